@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- generate tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Runs the lib2to3-converted reference (see oracle/ref_py3.py; build container
+only -- needs /root/reference) on seeded inputs and stores inputs + outputs.
+Only numbers are written; no reference source enters the repo.
+
+    python oracle/make_golden.py            # (re)writes tests/golden/*.npz
+
+Fixtures (all float64, ref = the reference's own functions):
+  ei_small_*.npz   GPEIChooser.compute_ei / GPEIOptChooser.ei_over_hypers on
+                   seeded synthetic problems (several N, M, D, H), with the
+                   per-stage arrays the reference computes internally
+                   recomputed through its gp.Matern52 / cov.
+  ei_pending.npz   GPEIChooser.compute_ei pending branch (fixed randn matrix,
+                   obtained by seeding numpy.random right before the call).
+  ei_persec.npz    GPEIperSecChooser.compute_ei_per_s (+ the literal
+                   ei_over_hypers with its early return).
+  branin_c1.npz    BASELINE config 1: the reference Sobol grid
+                   (sobol_lib.i4_sobol_generate(2,1000,1).T), Branin values on
+                   the first 20 points, a seeded GPEIChooser.next() call: the
+                   slice-sampled hypers of each draw, overall_ei, chosen index.
+  slice_sampler.npz  util.slice_sample traces under a seeded RNG.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import numpy.random as npr
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_py3  # noqa: E402
+from spearmint_amd.synthetic import synthetic_problem  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _mk_chooser(mod, cls, tmp, **kw):
+    ch = getattr(mod, cls)(tmp, **kw)
+    return ch
+
+
+def _set(ch, hyper):
+    ch.mean, ch.noise, ch.amp2, ch.ls = hyper[0], hyper[1], hyper[2], hyper[3:].copy()
+
+
+def gen_ei_small(mods, tmp):
+    cases = [  # name, N, M, D, H, seed
+        ("a", 24, 300, 2, 3, 11),
+        ("b", 64, 500, 8, 4, 12),
+        ("c", 200, 700, 5, 3, 13),
+        ("d", 130, 257, 32, 2, 14),
+    ]
+    for name, N, M, D, H, seed in cases:
+        comp, cand, vals, hypers = synthetic_problem(N, M, D, H, seed)
+        ch = _mk_chooser(mods["GPEIChooser"], "GPEIChooser", tmp, mcmc_iters=H)
+        ch.D = D
+        pend = np.zeros((0, D))
+        ei = np.zeros((M, H))
+        K = np.zeros((H, N, N)); Kstar = np.zeros((H, N, M))
+        for h in range(H):
+            _set(ch, hypers[h])
+            ei[:, h] = ch.compute_ei(comp, pend, cand, vals)
+            K[h] = ch.cov(comp) + ch.noise * np.eye(N)
+            Kstar[h] = ch.cov(comp, cand)
+        # the Opt chooser's ei_over_hypers must agree (same math)
+        opt = _mk_chooser(mods["GPEIOptChooser"], "GPEIOptChooser", tmp, mcmc_iters=H)
+        opt.D = D
+        opt.hyper_samples = [(h[0], h[1], h[2], h[3:].copy()) for h in hypers]
+        ei_opt = opt.ei_over_hypers(comp, pend, cand, vals)
+        assert np.array_equal(ei, ei_opt)
+        best = int(np.argmax(np.mean(ei, axis=1)))
+        extra = dict(K=K, Kstar=Kstar) if name == "a" else {}
+        np.savez_compressed(os.path.join(OUT, "ei_small_%s.npz" % name),
+                            comp=comp, cand=cand, vals=vals, hypers=hypers,
+                            ei=ei, best=best, **extra)
+        # keep __del__ quiet
+        _set(ch, hypers[0]); _set(opt, hypers[0])
+
+
+def gen_pending(mods, tmp):
+    N, M, D, H, P, S = 40, 200, 3, 2, 3, 7
+    comp, cand, vals, hypers = synthetic_problem(N, M, D, H, 21)
+    pend = np.random.RandomState(22).rand(P, D)
+    ch = _mk_chooser(mods["GPEIChooser"], "GPEIChooser", tmp, mcmc_iters=H, pending_samples=S)
+    ch.D = D
+    ei = np.zeros((M, H)); z = np.zeros((H, P, S))
+    for h in range(H):
+        _set(ch, hypers[h])
+        npr.seed(100 + h)
+        z[h] = npr.randn(P, S)
+        npr.seed(100 + h)
+        ei[:, h] = ch.compute_ei(comp, pend, cand, vals)
+    np.savez_compressed(os.path.join(OUT, "ei_pending.npz"), comp=comp, cand=cand, pend=pend,
+                        vals=vals, hypers=hypers, randn=z, ei=ei)
+
+
+def gen_persec(mods, tmp):
+    N, M, D, H = 50, 300, 4, 3
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(N, M, D, H, 31, per_sec=True)
+    ch = _mk_chooser(mods["GPEIperSecChooser"], "GPEIperSecChooser", tmp, mcmc_iters=H)
+    ch.D = D
+    pend = np.zeros((0, D))
+    ei = np.zeros((M, H))
+    for h in range(H):
+        _set(ch, hypers[h])
+        ch.time_mean, ch.time_noise, ch.time_amp2, ch.time_ls = th[h, 0], th[h, 1], th[h, 2], th[h, 3:].copy()
+        ei[:, h] = ch.compute_ei_per_s(comp, pend, cand, vals, log_durs)
+    ch.hyper_samples = [(h[0], h[1], h[2], h[3:].copy()) for h in hypers]
+    ch.time_hyper_samples = [(h[0], h[1], h[2], h[3:].copy()) for h in th]
+    literal = ch.ei_over_hypers(comp, pend, cand, vals, log_durs)  # early-return bug: draw 0 only
+    np.savez_compressed(os.path.join(OUT, "ei_persec.npz"), comp=comp, cand=cand, vals=vals,
+                        hypers=hypers, log_durs=log_durs, time_hypers=th, ei=ei, literal=literal)
+
+
+def branin(x0, x1):
+    """examples/braninpy/branin.py:6-16 on the unit-cube point the driver
+    passes in (config.pb: X is FLOAT size 2 in [0,1])."""
+    a = x0 * 15
+    b = (x1 * 15) - 5
+    return (np.square(b - (5.1 / (4 * np.square(np.pi))) * np.square(a) + (5 / np.pi) * a - 6)
+            + 10 * (1 - (1. / (8 * np.pi))) * np.cos(a) + 10)
+
+
+def gen_branin_c1(mods, tmp):
+    """Config 1: 2-D Branin, 20 observations, grid 1000, mcmc_iters 10,
+    GPEIChooser.next driven exactly as attempt_dispatch does (S/main.py:205-210,
+    :254): grid = i4_sobol_generate(2,1000,1).T, values NaN except completed."""
+    sob = mods["sobol_lib"]
+    grid = np.transpose(sob.i4_sobol_generate(2, 1000, 1))
+    G = grid.shape[0]
+    values = np.zeros(G) + np.nan
+    durations = np.zeros(G) + np.nan
+    status = np.zeros(G, dtype=int)          # 0 candidate, 2 complete
+    for i in range(20):
+        values[i] = branin(grid[i, 0], grid[i, 1])
+        durations[i] = 1.0
+        status[i] = 2
+    candidates = np.nonzero(status == 0)[0]
+    pending = np.nonzero(status == 1)[0]
+    complete = np.nonzero(status == 2)[0]
+
+    H = 10
+    mod = mods["GPEIChooser"]
+    # The reference sampler itself occasionally dies on raw Branin values
+    # ("Slice sampler shrank to zero!", S/util.py:68-69); take the first seed
+    # from 1234 upwards for which the reference's own next() completes.
+    for seed in range(1234, 1300):
+        # fresh expt_dir each time: GPEIChooser.__del__ pickles its state into
+        # expt_dir and _real_init would pick a stale one up (GPEIChooser.py:66-98)
+        ch = mod.GPEIChooser(tempfile.mkdtemp(prefix="spx_golden_c1_"), mcmc_iters=H)
+        hyp = []; eis = []
+        orig_ei = ch.compute_ei
+
+        def rec_ei(comp, pend, cand, vals, ch=ch, orig_ei=orig_ei, hyp=hyp, eis=eis):
+            hyp.append(np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)))
+            e = orig_ei(comp, pend, cand, vals)
+            eis.append(e.copy())
+            return e
+        ch.compute_ei = rec_ei
+        npr.seed(seed)
+        try:
+            job = ch.next(grid, values, durations, candidates, pending, complete)
+        except Exception as e:  # reference failure, try next seed
+            print("seed", seed, "reference raised:", e)
+            ch.ls = np.ones(2); ch.amp2 = ch.noise = ch.mean = 0.0
+            continue
+        break
+    np.savez_compressed(os.path.join(OUT, "branin_c1.npz"), grid=grid, values=values,
+                        durations=durations, candidates=candidates, pending=pending,
+                        complete=complete, hypers=np.array(hyp), ei=np.array(eis).T,
+                        job=int(job), seed=seed)
+
+
+def gen_slice(mods, tmp):
+    util = mods["util"]
+    comp, cand, vals, hypers = synthetic_problem(30, 10, 3, 1, 41)
+    gp = mods["gp"]
+    import scipy.linalg as spla
+
+    def lp_ls(ls):
+        if np.any(ls < 0) or np.any(ls > 2):
+            return -np.inf
+        c = 1.3 * (gp.Matern52(ls, comp, None) + 1e-6 * np.eye(30)) + 1e-3 * np.eye(30)
+        chol = spla.cholesky(c, lower=True)
+        solve = spla.cho_solve((chol, True), vals - 0.1)
+        return -np.sum(np.log(np.diag(chol))) - 0.5 * np.dot(vals - 0.1, solve)
+
+    npr.seed(77)
+    xs = [np.ones(3)]
+    for _ in range(5):
+        xs.append(util.slice_sample(xs[-1], lp_ls, compwise=True))
+    npr.seed(78)
+    ys = [np.array([0.3, 1.0, 0.5])]
+    for _ in range(5):
+        ys.append(util.slice_sample(ys[-1], lambda v: -0.5 * np.sum((v - 0.2) ** 2) / 0.3, compwise=False))
+    np.savez_compressed(os.path.join(OUT, "slice_sampler.npz"), comp=comp, vals=vals,
+                        compwise=np.array(xs), joint=np.array(ys),
+                        lp_at_ones=lp_ls(np.ones(3)))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    mods = ref_py3.load()
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_slice):
+        gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
