@@ -1,0 +1,146 @@
+/*
+ * spx.h -- C ABI of libspx.so, the MI355X (gfx950) GP-EI engine behind the
+ * Spearmint chooser plugin API.
+ *
+ * Boundary.  The reference has no FFI: its choosers
+ * call numpy/scipy in-process.  This library replaces exactly the block
+ *
+ *     for mcmc_iter in range(mcmc_iters): overall_ei[:, i] = compute_ei(...)
+ *     best_cand = argmax(mean(overall_ei, axis=1))
+ *
+ * of  spearmint/spearmint/chooser/GPEIChooser.py:143-153,
+ *     GPEIOptChooser.py:331-341 (+ :269-271, :293-294),
+ *     GPEIperSecChooser.py:284-302,
+ * i.e. per hyper-parameter draw:  gp.Matern52/dist2 (gp.py:34-54,120-127),
+ * chooser cov (GPEIChooser.py:117-122), spla.cholesky (:191), cho_solve (:194),
+ * solve_triangular (:195), predictive mean/variance (:198-199), EI (:202-206).
+ * The Python choosers in spearmint_amd/chooser/ bind it with ctypes
+ * (see INTEGRATION.md for the stub a maintainer would add to the reference).
+ *
+ * Conventions: plain C, caller-owned buffers, row-major float64, int64 sizes.
+ * No torch types.  Every function returns an int status: 0 = ok, <0 = error
+ * (spx_last_error() gives the text).  No exceptions or exit() cross the ABI.
+ * One handle = one GPU = one HIP stream; calls on a handle are serialized by
+ * the caller.  All calls are synchronous unless stated.
+ *
+ * Hyper-parameter row layout, everywhere: [mean, noise, amp2, ls[0..D)]
+ * (the tuple order of GPEIOptChooser.py:628), H rows of (3 + D) doubles.
+ */
+#ifndef SPX_H
+#define SPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spx_handle spx_handle;
+
+/* status codes */
+#define SPX_OK            0
+#define SPX_ERR_ARG      -1   /* bad argument / call order                     */
+#define SPX_ERR_HIP      -2   /* HIP runtime error (no device, OOM, ...)        */
+#define SPX_ERR_NOT_PD   -3   /* covariance not positive definite == the
+                                 numpy.linalg.LinAlgError spla.cholesky raises
+                                 (GPEIChooser.py:191); see spx_not_pd_info()     */
+
+/* flags for spx_ei_run / spx_ei_grid */
+#define SPX_FLAG_PER_SEC     1   /* divide EI by exp(predicted log duration)
+                                    (GPEIperSecChooser.py:437-491); needs
+                                    spx_set_time_model()                         */
+#define SPX_FLAG_KEEP_MOMENTS 2  /* keep func_m / func_v per (draw, candidate)
+                                    for spx_get_moments() (test / debug)          */
+#define SPX_FLAG_TIMING      4   /* bracket every kernel launch with HIP events
+                                    on the handle's stream (spx_get_timings)      */
+
+/* ---- lifetime ---------------------------------------------------------- */
+/* Create an engine on HIP device `device_id` (lazy: the first call that needs
+ * the GPU initialises it, so the handle can be created before a fork).       */
+int  spx_create(int device_id, spx_handle** out);
+void spx_destroy(spx_handle* h);
+const char* spx_last_error(void);
+int  spx_version(void);
+/* number of visible HIP devices, or <0 */
+int  spx_device_count(void);
+
+/* ---- resident-data API (what bench.py times: inputs already in HBM) ----- */
+/* comp = grid[complete,:] (N x D), vals = values[complete] (N)
+ * -- GPEIChooser.py:135-138.                                                  */
+int spx_set_observations(spx_handle* h, const double* comp, const double* vals,
+                         int64_t N, int32_t D);
+/* cand = grid[candidates,:] (M x D) -- GPEIChooser.py:136.  `index_base` is
+ * added to local candidate indices in results (a rank that owns candidate
+ * rows [base, base+M) of a sharded grid passes base).                         */
+int spx_set_candidates(spx_handle* h, const double* cand, int64_t M, int32_t D,
+                       int64_t index_base);
+/* H hyper-parameter draws, rows [mean, noise, amp2, ls...] */
+int spx_set_hypers(spx_handle* h, const double* hypers, int32_t H);
+/* second GP on log durations (GPEIperSecChooser.py:176, :437-458):
+ * log_durs (N), time_hypers H x (3+D).  Pass NULLs to clear.                  */
+int spx_set_time_model(spx_handle* h, const double* log_durs,
+                       const double* time_hypers);
+
+/* Hot path, stage 1: for every draw build K(X,X)+noise (gp.py:34-54,120-127;
+ * GPEIChooser.py:186,190), factor it (:191), and form what the solves need
+ * (:194).  Returns SPX_ERR_NOT_PD like spla.cholesky raising LinAlgError.     */
+int spx_factor(spx_handle* h);
+/* Hot path, stage 2: K(X*,X) (:187), triangular solve (:195), predictive
+ * mean/variance (:198-199), EI (:202-206) for every (candidate, draw); then the
+ * MCMC mean and the argmax (:153).  Results stay on the device.               */
+int spx_ei_run(spx_handle* h, int32_t flags);
+
+/* results of the last spx_ei_run */
+/* best_idx = index_base + argmax_c mean_h EI[c,h]  with numpy's rule (first NaN
+ * wins, else first maximum); best_val = that mean EI.                         */
+int spx_get_best(spx_handle* h, int64_t* best_idx, double* best_val);
+int spx_get_ei_mean(spx_handle* h, double* out /* M */);
+/* overall_ei exactly as the reference lays it out: M x H, row-major           */
+int spx_get_ei_draws(spx_handle* h, double* out /* M*H */);
+
+/* ---- one-shot convenience: host buffers in, results out ------------------ */
+/* == ei_over_hypers + argmax(mean) (GPEIOptChooser.py:331-341, :294).
+ * ei_mean_out (M) and ei_draw_out (M x H) may be NULL.                         */
+int spx_ei_grid(spx_handle* h,
+                const double* comp, const double* vals, int64_t N, int32_t D,
+                const double* cand, int64_t M,
+                const double* hypers, int32_t H, int32_t flags,
+                double* ei_mean_out, double* ei_draw_out,
+                int64_t* best_idx, double* best_val);
+/* == GPEIperSecChooser.ei_over_hypers with all draws evaluated (:284-302) */
+int spx_ei_per_sec_grid(spx_handle* h,
+                const double* comp, const double* vals, const double* log_durs,
+                int64_t N, int32_t D, const double* cand, int64_t M,
+                const double* hypers, const double* time_hypers, int32_t H,
+                int32_t flags, double* ei_mean_out, double* ei_draw_out,
+                int64_t* best_idx, double* best_val);
+
+/* ---- building blocks (per-stage parity tests, "next" rows) --------------- */
+/* After spx_factor: K + noise I (N x N, full symmetric), its lower Cholesky
+ * factor L (N x N, strict upper = 0) and alpha = K^-1 (vals - mean) (N) of
+ * draw `draw` (time model: draw + H).  Any pointer may be NULL.               */
+int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* alpha);
+/* K(X*,X) of draw `draw` for candidates [c0, c0+nc): N x nc row-major.         */
+int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, double* out);
+/* func_m, func_v (M each) of draw `draw`; needs SPX_FLAG_KEEP_MOMENTS.          */
+int spx_get_moments(spx_handle* h, int32_t draw, double* func_m, double* func_v);
+/* GP marginal log-likelihood data term  -sum(log diag L) - 0.5 r' K^-1 r  for
+ * each resident draw (GPEIChooser.py:281-285): out has H entries, -inf where
+ * the covariance is not PD.  Needs spx_set_observations + spx_set_hypers.      */
+int spx_gp_logprob(spx_handle* h, double* out);
+/* which draw / pivot failed in the last SPX_ERR_NOT_PD                         */
+int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot);
+
+/* ---- measurement ---------------------------------------------------------- */
+/* Per-kernel accumulated HIP-event time of the last spx_factor + spx_ei_run
+ * executed with SPX_FLAG_TIMING.  Fills up to n entries of ms[] / launches[]
+ * in the order of spx_timing_name(i); returns the number of stages.            */
+int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n);
+const char* spx_timing_name(int i);
+/* tuning knobs (bytes of the K(X*,X) staging buffer; 0 = default).            */
+int spx_set_option(spx_handle* h, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPX_H */

@@ -1,0 +1,361 @@
+// Batched blocked left-looking Cholesky + triangular inverse for gfx950.
+//
+// Replaces, for all hyper-parameter draws at once,
+//     obsv_chol = spla.cholesky(obsv_cov, lower=True)        GPEIChooser.py:191
+//     alpha     = spla.cho_solve((obsv_chol, True), vals-mean)          :194
+// and prepares  W = L^-1  so that  spla.solve_triangular(L, K*) (:195) becomes
+// the dense fp64 MFMA GEMM  W K*  of predict_kernels.hip.
+//
+// Matrices: [nh][Np][Np] row-major, Np a multiple of 128, block size NB = 64.
+// Left-looking, one block column k at a time (two launches per k):
+//   k_chol_diag   1 workgroup / draw : S = K_kk - L_k,:k L_k,:k^T (MFMA, panels
+//                 staged in LDS), in-LDS Cholesky of the 64x64 block by one
+//                 wavefront (column scale + rank-1 update, the pivot column
+//                 broadcast lane-to-lane with v_readlane), then its inverse.
+//   k_chol_panel  1 workgroup / (row block > k, draw):
+//                 L_rk = (K_rk - L_r,:k L_k,:k^T) L_kk^-T          (MFMA)
+// k_trinv: W = L^-1 by block columns (one launch), stored transposed
+//   WT[j][i] = W[i][j]  so the predict GEMM reads both operands K-major.
+#include "common.h"
+
+#define NB SPX_NB
+#define LDP 66   // LDS row stride (doubles) for MFMA operand tiles: 16 rows x 2 cols hit 32 distinct 8-byte banks
+#define LDS_S 65 // LDS row stride for the lane-per-row factorization (column access conflict-free)
+
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+// copy a 64x64 tile (row stride ld in global) into LDS [64][LDP]; 256 threads
+__device__ __forceinline__ void tile_to_lds(const double* __restrict__ g, size_t ld, double* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = threadIdx.x + 256 * q;  // double2 units
+        const int row = idx >> 5, c2 = idx & 31;
+        const d2 v = *reinterpret_cast<const d2*>(g + (size_t)row * ld + 2 * c2);
+        *reinterpret_cast<d2*>(lds + row * LDP + 2 * c2) = v;
+    }
+}
+
+// acc[nt] (+)= sign * A_lds[16w+li][:] . B_lds[16nt+li][:]^T over the 64-deep tile
+__device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B_lds, d4 acc[4],
+                                            int wave, int g, int li, bool negate)
+{
+#pragma unroll 4
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        double a = A_lds[(16 * wave + li) * LDP + k0 + g];
+        if (negate) a = -a;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const double b = B_lds[(16 * nt + li) * LDP + k0 + g];
+            acc[nt] = MFMA_F64(a, b, acc[nt]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ Lm, double* __restrict__ Dinv,
+                                                   int* __restrict__ info, int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* P = smem;                  // [64][LDP]
+    double* S = P + NB * LDP;          // [64][LDS_S]
+    double* X = S + NB * LDS_S;        // [64][LDS_S]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x;
+    const int nblk = Np / NB;
+    double* Lh = Lm + (size_t)h * Np * Np;
+    const size_t kb0 = (size_t)k * NB;
+
+    // S = K_kk - sum_p L_kp L_kp^T
+    d4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[nt][r] = Lh[(kb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
+    for (int p = 0; p < k; ++p) {
+        __syncthreads();
+        tile_to_lds(Lh + kb0 * Np + (size_t)p * NB, Np, P);
+        __syncthreads();
+        mma_tile_64(P, P, acc, wave, g, li, true);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(16 * wave + g + 4 * r) * LDS_S + 16 * nt + li] = acc[nt][r];
+    __syncthreads();
+
+    if (wave == 0) {
+        // --- unblocked Cholesky of S, lane i owns row i ---------------------
+        const int i = lane;
+        int bad = 0;
+        for (int j = 0; j < NB; ++j) {
+            double d = S[j * LDS_S + j];
+            if (!(d > 0.0)) {  // also catches NaN, like LAPACK dpotrf's (ajj <= 0 || isnan)
+                if (!bad) bad = (int)kb0 + j + 1;
+                d = 1.0;
+            }
+            const double sd = sqrt(d);
+            const double rinv = 1.0 / sd;
+            double lij = 0.0;
+            if (i > j) lij = S[i * LDS_S + j] * rinv;
+            else if (i == j) lij = sd;
+            S[i * LDS_S + j] = lij;
+            for (int kc = j + 1; kc < NB; ++kc) {
+                const double lk = readlane_f64(lij, kc);
+                if (i >= kc) S[i * LDS_S + kc] -= lij * lk;
+            }
+        }
+        if (bad && lane == 0) {
+            if (info[h] == 0) info[h] = bad;
+        }
+        // --- X = L_kk^-1, lane c owns column c -------------------------------
+        const int c = lane;
+        for (int r = 0; r < NB; ++r) {
+            double a = (r == c) ? 1.0 : 0.0;
+            for (int p = 0; p < r; ++p) {
+                const double lrp = S[r * LDS_S + p];           // broadcast
+                const double xp = X[p * LDS_S + c];            // own column (0 above the diagonal)
+                a -= lrp * xp;
+            }
+            const double x = (r >= c) ? a / S[r * LDS_S + r] : 0.0;
+            X[r * LDS_S + c] = x;
+        }
+    }
+    __syncthreads();
+    // write L_kk (upper part zero) and its inverse
+    double* Dk = Dinv + ((size_t)h * nblk + k) * NB * NB;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+        const int row = idx >> 6, col = idx & 63;
+        Lh[(kb0 + row) * Np + kb0 + col] = (col <= row) ? S[row * LDS_S + col] : 0.0;
+        Dk[idx] = X[row * LDS_S + col];
+    }
+}
+
+void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh)
+{
+    const size_t lds = (size_t)(NB * LDP + 2 * NB * LDS_S) * sizeof(double);
+    hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k);
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ Lm,
+                                                    const double* __restrict__ Dinv, int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;             // [64][LDP]
+    double* B = smem + NB * LDP;  // [64][LDP]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.y;
+    const int nblk = Np / NB;
+    const int rb = k + 1 + blockIdx.x;
+    double* Lh = Lm + (size_t)h * Np * Np;
+    const size_t kb0 = (size_t)k * NB, rb0 = (size_t)rb * NB;
+
+    d4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[nt][r] = Lh[(rb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
+    for (int p = 0; p < k; ++p) {
+        __syncthreads();
+        tile_to_lds(Lh + rb0 * Np + (size_t)p * NB, Np, A);
+        tile_to_lds(Lh + kb0 * Np + (size_t)p * NB, Np, B);
+        __syncthreads();
+        mma_tile_64(A, B, acc, wave, g, li, true);
+    }
+    __syncthreads();
+    // L_rk = S L_kk^-T :  out[i][n] = sum_q S[i][q] Dinv[n][q]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
+    tile_to_lds(Dinv + ((size_t)h * nblk + k) * NB * NB, NB, B);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+    mma_tile_64(A, B, acc, wave, g, li, false);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Lh[(rb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li] = acc[nt][r];
+}
+
+void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh)
+{
+    const int nblk = Np / NB;
+    if (nblk - k - 1 <= 0) return;
+    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);
+    hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k - 1, nh), dim3(256), lds, s, L, Dinv, Np, k);
+}
+
+// ---------------------------------------------------------------------------
+// W = L^-1, block column jb per workgroup, output transposed: WT[j][i] = W[i][j].
+//   W_jj = Dinv_j ;  W_ij = -Dinv_i * sum_{p=j}^{i-1} L_ip W_pj     (i > j)
+// computed as transposes so both stores and loads are row-contiguous:
+//   Tt[n][i'] = sum_p sum_q WT[j0+n][p0+q] L[i0+i'][p0+q]
+//   WT[j0+n][i0+i''] = - sum_{i'} Tt[n][i'] Dinv_i[i''][i']
+// WT must be zero-initialised by the caller (entries above the block diagonal
+// inside a 128-wide GEMM row block are read by the predict GEMM).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trinv(const double* __restrict__ Lm,
+                                               const double* __restrict__ Dinv,
+                                               double* __restrict__ WT, int Np)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;
+    double* B = smem + NB * LDP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.y;
+    const int nblk = Np / NB;
+    // heavy block columns (small jb) first
+    const int jb = blockIdx.x;
+    const double* Lh = Lm + (size_t)h * Np * Np;
+    double* Wh = WT + (size_t)h * Np * Np;
+    const double* Dh = Dinv + (size_t)h * nblk * NB * NB;
+    const size_t j0 = (size_t)jb * NB;
+
+    // diagonal block: WT[j0+n][j0+i] = Dinv_j[i][n]
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+        const int n = idx >> 6, i = idx & 63;
+        Wh[(j0 + n) * Np + j0 + i] = Dh[(size_t)jb * NB * NB + i * NB + n];
+    }
+    for (int ib = jb + 1; ib < nblk; ++ib) {
+        const size_t i0 = (size_t)ib * NB;
+        d4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int p = jb; p < ib; ++p) {
+            __syncthreads();  // also orders the previous iteration's WT stores before these loads
+            tile_to_lds(Wh + j0 * Np + (size_t)p * NB, Np, A);
+            tile_to_lds(Lh + i0 * Np + (size_t)p * NB, Np, B);
+            __syncthreads();
+            mma_tile_64(A, B, acc, wave, g, li, false);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
+        tile_to_lds(Dh + (size_t)ib * NB * NB, NB, B);
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+        mma_tile_64(A, B, acc, wave, g, li, true);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Wh[(j0 + 16 * wave + g + 4 * r) * Np + i0 + 16 * nt + li] = acc[nt][r];
+        __threadfence_block();
+    }
+}
+
+void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh)
+{
+    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);
+    hipLaunchKernelGGL(k_trinv, dim3(Np / NB, nh), dim3(256), lds, s, L, Dinv, WT, Np);
+}
+
+// ---------------------------------------------------------------------------
+// gamma = W (vals - mean)   (one thread per row i, coalesced over i)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gamma(const double* __restrict__ WT,
+                                               const double* __restrict__ vals /*[nh][Np] or [Np]*/,
+                                               int vals_stride, const double* __restrict__ htab,
+                                               double* __restrict__ gamma, int N, int Np)
+{
+    __shared__ double r[256];
+    const int h = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double* Wh = WT + (size_t)h * Np * Np;
+    const double mean = htab[h * SPX_HT + 0];
+    const double* vh = vals + (size_t)h * vals_stride;
+    double acc = 0.0;
+    const int jmax = blockIdx.x * 256 + 255;  // rows this block needs: j <= i
+    for (int jb = 0; jb <= jmax; jb += 256) {
+        __syncthreads();
+        const int jj = jb + threadIdx.x;
+        r[threadIdx.x] = (jj < N) ? (vh[jj] - mean) : 0.0;
+        __syncthreads();
+        const int jn = (i < Np) ? min(256, i - jb + 1) : 0;
+        for (int t = 0; t < jn; ++t) acc += Wh[(size_t)(jb + t) * Np + i] * r[t];
+    }
+    if (i < Np) gamma[(size_t)h * Np + i] = acc;
+}
+
+void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
+                  double* gamma, int N, int Np, int nh)
+{
+    hipLaunchKernelGGL(k_gamma, dim3(Np / 256 + (Np % 256 != 0), nh), dim3(256), 0, s, WT, vals, 0,
+                       htab, gamma, N, Np);
+}
+
+// alpha = W^T gamma  == K^-1 (vals - mean);  one wavefront per row j of WT
+__global__ __launch_bounds__(256) void k_alpha(const double* __restrict__ WT,
+                                               const double* __restrict__ gamma,
+                                               double* __restrict__ alpha, int Np)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.y;
+    const int j = blockIdx.x * 4 + wave;
+    const double* row = WT + ((size_t)h * Np + j) * Np;
+    const double* gh = gamma + (size_t)h * Np;
+    double acc = 0.0;
+    for (int i = (j & ~63) + lane; i < Np; i += 64)
+        if (i >= j) acc += row[i] * gh[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) alpha[(size_t)h * Np + j] = acc;
+}
+
+void launch_alpha(hipStream_t s, const double* WT, const double* gamma, double* alpha, int Np, int nh)
+{
+    hipLaunchKernelGGL(k_alpha, dim3(Np / 4, nh), dim3(256), 0, s, WT, gamma, alpha, Np);
+}
+
+// lp = -sum log diag(L) - 0.5 |gamma|^2   (GPEIChooser.py:284); -inf if not PD
+__global__ __launch_bounds__(256) void k_logprob(const double* __restrict__ Lm,
+                                                 const double* __restrict__ gamma,
+                                                 const int* __restrict__ info,
+                                                 double* __restrict__ out, int N, int Np)
+{
+    __shared__ double red[2][256];
+    const int h = blockIdx.x;
+    double sl = 0.0, sq = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        sl += log(Lm[((size_t)h * Np + i) * Np + i]);
+        const double gi = gamma[(size_t)h * Np + i];
+        sq += gi * gi;
+    }
+    red[0][threadIdx.x] = sl;
+    red[1][threadIdx.x] = sq;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[h] = info[h] ? -__builtin_inf() : (-red[0][0] - 0.5 * red[1][0]);
+}
+
+void launch_logprob(hipStream_t s, const double* L, const double* gamma, const int* info,
+                    double* out, int Np, int nh)
+{
+    // N is recovered on the host side: pad rows have L_ii = 1 (log 0) and gamma = 0
+    hipLaunchKernelGGL(k_logprob, dim3(nh), dim3(256), 0, s, L, gamma, info, out, Np, Np);
+}

@@ -1,0 +1,62 @@
+// Shared device/host definitions for libspx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) * B(4x16) + C.
+//   A: lane l supplies A[i = l & 15][k = l >> 4]
+//   B: lane l supplies B[k = l >> 4][n = l & 15]
+//   C/D: reg r of lane l is element [row = (l >> 4) + 4 r][col = l & 15]
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// geometry shared by host and device code
+#define SPX_NB 64        // Cholesky / inverse block size
+#define SPX_BM 128       // predict GEMM: rows (observations) per workgroup tile
+#define SPX_BN 128       // predict GEMM: candidates per workgroup tile
+#define SPX_BK 16        // predict GEMM: contraction depth per LDS stage
+#define SPX_PADN 128     // observations are padded to a multiple of this
+
+// device hyper table row: [mean, noise, amp2, amp2*(1+1e-6)]
+#define SPX_HT 4
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- launchers (defined in the *.hip translation units) ---------------------
+// cov_kernels.hip
+void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp,
+                       const double* ls /*[nh][ls_stride]*/, int ls_stride, int nh, double factor,
+                       double* xs /*[nh][n_pad][Dp]*/, double* sumsq /*[nh][n_pad]*/);
+void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const double* X2s,
+                     const double* htab, double* K, int N, int Np, int Dp, int nh);
+void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
+                      const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
+                      int Dp, int nh);
+void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
+                       const double* s2, const double* htab, const double* alpha, double* out,
+                       int N, int Np, int Mc, int Dp, int nh);
+
+// chol_kernels.hip
+void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh);
+void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh);
+void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh);
+void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
+                  double* gamma, int N, int Np, int nh);
+void launch_alpha(hipStream_t s, const double* WT, const double* gamma, double* alpha, int Np, int nh);
+void launch_logprob(hipStream_t s, const double* L, const double* gamma, const int* info,
+                    double* out, int Np, int nh);
+
+// predict_kernels.hip
+void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
+                         double* part_ss, double* part_bg, int Np, int Mc, int nh);
+void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part_bg,
+                        const double* htab, const double* time_m, double best, double* ei_draw,
+                        double* mom_m, double* mom_v, int nrb, int Mc, int nh, int64_t c0,
+                        int64_t M, int64_t Mp, int h0);
+void launch_mean_over_draws(hipStream_t s, const double* ei_draw, double* ei_mean, int64_t M,
+                            int64_t Mp, int H);
+void launch_argmax(hipStream_t s, const double* v, int64_t M, double* blk_val, int64_t* blk_idx,
+                   double* out_val, int64_t* out_idx);
+int argmax_blocks(int64_t M);

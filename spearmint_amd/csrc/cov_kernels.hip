@@ -1,0 +1,230 @@
+// ARD Matern-5/2 covariance kernels for gfx950 (hand-written HIP, wave64).
+//
+// Reference arithmetic being reproduced (spearmint/spearmint/gp.py:34-54 dist2,
+// :120-127 Matern52; chooser cov GPEIChooser.py:117-122):
+//     xx  = x / ls                               (true division)
+//     r2  = max(-((xx1 . (2 xx2)^T - |xx1|^2) - |xx2|^2), 0) ; r2 = |r2| ; r = sqrt(r2)
+//     k   = (1 + sqrt5 r + 5/3 r2) * exp(-sqrt5 r)
+//     K_self  = amp2 (k + 1e-6 I) + noise I      K_cross = amp2 k
+//
+// The pairwise Gram term xx1 . (2 xx2)^T is an fp64 MFMA GEMM
+// (v_mfma_f64_16x16x4_f64, contraction over the padded input dimension), the
+// norm / Matern part is the epilogue on the accumulator registers, so the
+// squared-distance matrix never exists in memory.
+#include "common.h"
+
+#define SQRT5 2.23606797749978969641  // == np.sqrt(5.0) (gp.py:32)
+
+// ---------------------------------------------------------------------------
+// x / ls, row norms.   One thread per (row, draw).
+//   xs[h][row][d]  = factor * (x[row][d] / ls[h][d])     (0 for pad rows / dims)
+//   sumsq[h][row]  = sum_d (x[row][d] / ls[h][d])^2
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scale_rows(
+    const double* __restrict__ x, int64_t n, int64_t n_pad, int D, int Dp,
+    const double* __restrict__ ls, int ls_stride, double factor,
+    double* __restrict__ xs, double* __restrict__ sumsq)
+{
+#pragma clang fp contract(off)
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (row >= n_pad) return;
+    double* o = xs + ((size_t)h * n_pad + row) * Dp;
+    const double* lsh = ls + (size_t)h * ls_stride;
+    double acc = 0.0;
+    if (row < n) {
+        const double* xr = x + (size_t)row * D;
+        for (int d = 0; d < D; ++d) {
+            const double v = xr[d] / lsh[d];
+            acc = acc + v * v;
+            o[d] = factor * v;
+        }
+        for (int d = D; d < Dp; ++d) o[d] = 0.0;
+    } else {
+        for (int d = 0; d < Dp; ++d) o[d] = 0.0;
+    }
+    sumsq[(size_t)h * n_pad + row] = acc;
+}
+
+void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp,
+                       const double* ls, int ls_stride, int nh, double factor,
+                       double* xs, double* sumsq)
+{
+    dim3 grid((unsigned)((n_pad + 255) / 256), nh);
+    hipLaunchKernelGGL(k_scale_rows, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride,
+                       factor, xs, sumsq);
+}
+
+// Matern-5/2 correlation from the Gram term and the two squared norms, in the
+// reference's operation order (no FMA contraction so each step rounds as numpy's).
+__device__ __forceinline__ double matern52_corr(double g, double s1, double s2)
+{
+#pragma clang fp contract(off)
+    const double t = (g - s1) - s2;
+    double r2 = fmax(-t, 0.0);
+    r2 = fabs(r2);
+    const double r = sqrt(r2);
+    const double poly = (1.0 + SQRT5 * r) + (5.0 / 3.0) * r2;
+    return poly * exp(-SQRT5 * r);
+}
+
+// ---------------------------------------------------------------------------
+// Covariance tile kernel.
+//   A side: observations, pre-scaled  Xs[h][Np][Dp], norms s1[h][Np]
+//   B side: columns, pre-scaled by 2  Cs[h][Mc][Dp], norms s2[h][Mc]
+//   out[h][j][c], row stride ldo.
+// Workgroup = 4 waves, tile = 128 rows (j) x 64 columns (c); wave w owns row
+// sub-tiles {w, w+4} (16 rows each) and all 4 column sub-tiles, so one A
+// fragment feeds 4 MFMAs.  Contraction index mapping: lane group g = lane>>4
+// contributes input dims [g*Q, g*Q+Q), Q = Dp/4, so every lane reads Q
+// consecutive doubles of "its" row (vector loads, no LDS needed: both operand
+// panels are a few KB and live in L1/L2).
+// MODE 0: cross-cov  amp2*k, pad rows -> 0
+// MODE 1: self-cov   amp2*(k + 1e-6 [j==c]) + noise [j==c], pad -> identity
+// MODE 2: cross-mean out[h][c] = exp( sum_j amp2*k[j][c]*alpha[h][j] + mean )
+// ---------------------------------------------------------------------------
+template <int MODE, int QC>
+__global__ __launch_bounds__(256) void k_cov(
+    const double* __restrict__ Xs, const double* __restrict__ s1,
+    const double* __restrict__ Cs, const double* __restrict__ s2,
+    const double* __restrict__ htab, const double* __restrict__ alpha,
+    double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.z;
+    const int c0 = blockIdx.x * 64;
+    const int Q = Dp >> 2;
+    const double* Xh = Xs + (size_t)h * Np * Dp;
+    const double* Ch = Cs + (size_t)h * Mc * Dp;
+    const double* s1h = s1 + (size_t)h * Np;
+    const double noise = htab[h * SPX_HT + 1];
+    const double amp2 = htab[h * SPX_HT + 2];
+
+    double s2v[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) s2v[nt] = s2[(size_t)h * Mc + c0 + 16 * nt + li];
+
+    double bf[4][QC];
+    if (nchunks == 1) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const double* p = Ch + (size_t)(c0 + 16 * nt + li) * Dp + g * Q;
+#pragma unroll
+            for (int q = 0; q < QC; ++q) bf[nt][q] = p[q];
+        }
+    }
+
+    // MODE 2 accumulates sum_j k[j][c] alpha[j] for this lane's column(s)
+    double colsum[4] = {0.0, 0.0, 0.0, 0.0};
+
+    const int jbeg = (MODE == 2) ? 0 : blockIdx.y * 128;
+    const int jend = (MODE == 2) ? Np : jbeg + 128;
+    for (int j0 = jbeg + wave * 16; j0 < jend; j0 += 64) {
+        d4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int ch = 0; ch < nchunks; ++ch) {
+            double af[QC];
+            const double* pa = Xh + (size_t)(j0 + li) * Dp + g * Q + ch * QC;
+#pragma unroll
+            for (int q = 0; q < QC; ++q) af[q] = pa[q];
+            if (nchunks > 1) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const double* p = Ch + (size_t)(c0 + 16 * nt + li) * Dp + g * Q + ch * QC;
+#pragma unroll
+                    for (int q = 0; q < QC; ++q) bf[nt][q] = p[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QC; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = MFMA_F64(af[q], bf[nt][q], acc[nt]);
+        }
+        // epilogue on the accumulator layout: row = j0 + g + 4 r, col = c0 + 16 nt + li
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + g + 4 * r;
+            const double s1v = s1h[j];
+            double av = 0.0;
+            if (MODE == 2) av = alpha[(size_t)h * Np + j];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int c = c0 + 16 * nt + li;
+                const double corr = matern52_corr(acc[nt][r], s1v, s2v[nt]);
+                if (MODE == 0) {
+                    double v = amp2 * corr;
+                    if (j >= N) v = 0.0;
+                    out[((size_t)h * Np + j) * ldo + c] = v;
+                } else if (MODE == 1) {
+#pragma clang fp contract(off)
+                    const double eye = (j == c) ? 1.0 : 0.0;
+                    double v = amp2 * (corr + 1e-6 * eye) + noise * eye;
+                    if (j >= N || c >= N) v = eye;
+                    out[((size_t)h * Np + j) * ldo + c] = v;
+                } else {
+                    // pad rows have alpha == 0 and finite corr
+                    colsum[nt] += (amp2 * corr) * av;
+                }
+            }
+        }
+    }
+
+    if (MODE == 2) {
+        __shared__ double red[4][64];
+        const double mean = htab[h * SPX_HT + 0];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            double v = colsum[nt];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) red[wave][16 * nt + li] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int c = threadIdx.x;
+            const double dot = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+            out[(size_t)h * Mc + c0 + c] = exp(dot + mean);
+        }
+    }
+}
+
+template <int MODE>
+static void launch_cov_mode(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
+                            const double* s2, const double* htab, const double* alpha, double* out,
+                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo)
+{
+    const int Q = Dp / 4;
+    dim3 grid(Mc / 64, (MODE == 2) ? 1 : Np / 128, nh);
+    dim3 block(256);
+#define SPX_COV_LAUNCH(QC_)                                                                        \
+    hipLaunchKernelGGL((k_cov<MODE, QC_>), grid, block, 0, s, Xs, s1, Cs, s2, htab, alpha, out, N, \
+                       Np, Mc, Dp, Q / QC_, ldo)
+    if (Q == 1) SPX_COV_LAUNCH(1);
+    else if (Q == 2) SPX_COV_LAUNCH(2);
+    else if (Q == 4) SPX_COV_LAUNCH(4);
+    else SPX_COV_LAUNCH(8);
+#undef SPX_COV_LAUNCH
+}
+
+void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
+                      const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
+                      int Dp, int nh)
+{
+    launch_cov_mode<0>(s, Xs, s1, Cs, s2, htab, nullptr, Kst, N, Np, Mc, Dp, nh, Mc);
+}
+
+// X2s = 2 * Xs (the reference multiplies the second operand by 2, gp.py:50)
+void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const double* X2s,
+                     const double* htab, double* K, int N, int Np, int Dp, int nh)
+{
+    launch_cov_mode<1>(s, Xs, s1, X2s, s1, htab, nullptr, K, N, Np, Np, Dp, nh, Np);
+}
+
+void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
+                       const double* s2, const double* htab, const double* alpha, double* out,
+                       int N, int Np, int Mc, int Dp, int nh)
+{
+    launch_cov_mode<2>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, Mc);
+}

@@ -1,0 +1,369 @@
+// Predictive variance / mean / EI kernels for gfx950.
+//
+// Reference (spearmint/spearmint/chooser/GPEIChooser.py):
+//     beta   = spla.solve_triangular(obsv_chol, cand_cross, lower=True)   :195
+//     func_m = np.dot(cand_cross.T, alpha) + self.mean                    :198
+//     func_v = self.amp2*(1+1e-6) - np.sum(beta**2, axis=0)               :199
+//     EI     = func_s*(u*ncdf + npdf)                                     :202-206
+//     best_cand = np.argmax(np.mean(overall_ei, axis=1))                  :153
+//
+// k_predict_gemm is the dominant kernel of the whole path: beta = W K* as an
+// fp64 MFMA GEMM (W = L^-1 from chol_kernels.hip, both operands K-major in
+// memory) whose epilogue reduces the accumulator tile to the two numbers per
+// candidate the posterior needs,
+//     sum_i beta[i][c]^2            and        sum_i beta[i][c] gamma[i]
+// (gamma = W (vals - mean), so the second one equals cand_cross^T alpha).
+// beta itself is never written to memory.
+#include "common.h"
+
+#define BM SPX_BM
+#define BN SPX_BN
+#define BK SPX_BK
+#define LDT 144  // LDS row stride (doubles): 128 + 16, so rows k and k+1 of a fragment land on disjoint bank halves
+
+// ---------------------------------------------------------------------------
+// C[i][c] = sum_{j <= i-block end} WT[j][i] * Kst[j][c]
+//   tile 128(i) x 128(c), 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles,
+//   K loop over j in steps of 16, register-staged double-buffered LDS.
+// Grid: 1-D, heaviest row blocks (largest ib = longest K loop) first.
+// part_ss / part_bg: [nrb][nh][Mc]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_predict_gemm(
+    const double* __restrict__ WT, const double* __restrict__ Kst,
+    const double* __restrict__ gamma, double* __restrict__ part_ss,
+    double* __restrict__ part_bg, int Np, int Mc, int nh, int ncb, int nrb)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                      // [2][BK][LDT]
+    double* Bs = smem + 2 * BK * LDT;       // [2][BK][LDT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int per_rb = ncb * nh;
+    const int bid = blockIdx.x;
+    const int ib = nrb - 1 - bid / per_rb;
+    const int rem = bid % per_rb;
+    const int h = rem / ncb;
+    const int cb = rem % ncb;
+
+    const double* Ag = WT + (size_t)h * Np * Np + (size_t)ib * BM;
+    const double* Bg = Kst + (size_t)h * Np * Mc + (size_t)cb * BN;
+    const int nk = (ib + 1) * (BM / BK);
+
+    // global->LDS staging map: 4 x 16 B per thread per operand tile (16 rows x 128 doubles)
+    const int lrow = tid >> 6;        // + 4 q
+    const int lcol = (tid & 63) * 2;  // doubles
+    d2 ra[4], rb[4];
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = lrow + 4 * q;
+        ra[q] = *reinterpret_cast<const d2*>(Ag + (size_t)row * Np + lcol);
+        rb[q] = *reinterpret_cast<const d2*>(Bg + (size_t)row * Mc + lcol);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = lrow + 4 * q;
+        *reinterpret_cast<d2*>(As + row * LDT + lcol) = ra[q];
+        *reinterpret_cast<d2*>(Bs + row * LDT + lcol) = rb[q];
+    }
+    __syncthreads();
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            const size_t j0 = (size_t)(kt + 1) * BK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t row = j0 + lrow + 4 * q;
+                ra[q] = *reinterpret_cast<const d2*>(Ag + row * Np + lcol);
+                rb[q] = *reinterpret_cast<const d2*>(Bg + row * Mc + lcol);
+            }
+        }
+        const double* Ac = As + cur * BK * LDT + 64 * wm + li;
+        const double* Bc = Bs + cur * BK * LDT + 64 * wn + li;
+#pragma unroll
+        for (int k0 = 0; k0 < BK; k0 += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = Ac[(k0 + g) * LDT + 16 * t];
+                b[t] = Bc[(k0 + g) * LDT + 16 * t];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA_F64(a[mt], b[nt], acc[mt][nt]);
+        }
+        if (more) {
+            double* An = As + (cur ^ 1) * BK * LDT;
+            double* Bn = Bs + (cur ^ 1) * BK * LDT;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = lrow + 4 * q;
+                *reinterpret_cast<d2*>(An + row * LDT + lcol) = ra[q];
+                *reinterpret_cast<d2*>(Bn + row * LDT + lcol) = rb[q];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: column sums of C^2 and C*gamma over this block's 128 rows ----
+    // accumulator layout: acc[mt][nt][r] = C[64 wm + 16 mt + g + 4 r][64 wn + 16 nt + li]
+    const double* gh = gamma + (size_t)h * Np + (size_t)ib * BM + 64 * wm;
+    double gam[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gam[mt][r] = gh[16 * mt + g + 4 * r];
+
+    double* red = smem;  // [2 (wm)][128][2]; safe: every wave passed the last barrier of the K loop
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        double ss = 0.0, bg = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = acc[mt][nt][r];
+                ss = fma(v, v, ss);
+                bg = fma(v, gam[mt][r], bg);
+            }
+        ss += __shfl_xor(ss, 16);
+        bg += __shfl_xor(bg, 16);
+        ss += __shfl_xor(ss, 32);
+        bg += __shfl_xor(bg, 32);
+        if (g == 0) {
+            const int c = 64 * wn + 16 * nt + li;
+            red[(wm * BN + c) * 2 + 0] = ss;
+            red[(wm * BN + c) * 2 + 1] = bg;
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        const double ss = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+        const double bg = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+        const size_t o = ((size_t)ib * nh + h) * Mc + (size_t)cb * BN + tid;
+        part_ss[o] = ss;
+        part_bg[o] = bg;
+    }
+}
+
+void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
+                         double* part_ss, double* part_bg, int Np, int Mc, int nh)
+{
+    const int ncb = Mc / BN, nrb = Np / BM;
+    const size_t lds = (size_t)(4 * BK * LDT) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_predict_gemm, dim3(ncb * nrb * nh), dim3(256), lds, s, WT, Kst, gamma,
+                       part_ss, part_bg, Np, Mc, nh, ncb, nrb);
+}
+
+// ---------------------------------------------------------------------------
+// EI from the partial sums.  Phi follows scipy.special.ndtr (cephes): erf for
+// |x|/sqrt2 < 1/sqrt2, erfc otherwise, so the lower tail keeps relative
+// accuracy; phi = exp(-u^2/2)/sqrt(2 pi) as scipy.stats.norm.pdf.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double ndtr_dev(double a)
+{
+#pragma clang fp contract(off)
+    const double x = a * 0.70710678118654752440;
+    const double z = fabs(x);
+    if (z < 0.70710678118654752440) return 0.5 + 0.5 * erf(x);
+    double y = 0.5 * erfc(z);
+    if (x > 0) y = 1.0 - y;
+    return y;
+}
+
+__device__ __forceinline__ double ei_dev(double func_m, double func_v, double best)
+{
+#pragma clang fp contract(off)
+    const double func_s = sqrt(func_v);  // NaN for func_v < 0, as np.sqrt
+    const double u = (best - func_m) / func_s;
+    const double ncdf = ndtr_dev(u);
+    const double npdf = exp(-(u * u) / 2.0) / 2.50662827463100050242;  // sqrt(2 pi)
+    return func_s * (u * ncdf + npdf);
+}
+
+// one thread per (candidate of the chunk, draw of the group)
+__global__ __launch_bounds__(256) void k_ei_finalize(
+    const double* __restrict__ part_ss, const double* __restrict__ part_bg,
+    const double* __restrict__ htab, const double* __restrict__ time_m /*[nh][Mc] or null*/,
+    double best, double* __restrict__ ei_draw /*[H][Mp]*/, double* __restrict__ mom_m,
+    double* __restrict__ mom_v, int nrb, int Mc, int nh, int64_t c0, int64_t M, int64_t Mp, int h0)
+{
+#pragma clang fp contract(off)
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    if (c >= Mc || c0 + c >= M) return;
+    double ss = 0.0, bg = 0.0;
+    for (int ib = 0; ib < nrb; ++ib) {
+        const size_t o = ((size_t)ib * nh + h) * Mc + c;
+        ss += part_ss[o];
+        bg += part_bg[o];
+    }
+    const double mean = htab[h * SPX_HT + 0];
+    const double prior_v = htab[h * SPX_HT + 3];  // amp2*(1+1e-6)
+    const double func_m = bg + mean;
+    const double func_v = prior_v - ss;
+    double ei = ei_dev(func_m, func_v, best);
+    if (time_m) ei = ei / time_m[(size_t)h * Mc + c];
+    const size_t o = (size_t)(h0 + h) * Mp + c0 + c;
+    ei_draw[o] = ei;
+    if (mom_m) {
+        mom_m[o] = func_m;
+        mom_v[o] = func_v;
+    }
+}
+
+void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part_bg,
+                        const double* htab, const double* time_m, double best, double* ei_draw,
+                        double* mom_m, double* mom_v, int nrb, int Mc, int nh, int64_t c0,
+                        int64_t M, int64_t Mp, int h0)
+{
+    hipLaunchKernelGGL(k_ei_finalize, dim3((Mc + 255) / 256, nh), dim3(256), 0, s, part_ss, part_bg,
+                       htab, time_m, best, ei_draw, mom_m, mom_v, nrb, Mc, nh, c0, M, Mp, h0);
+}
+
+// ---------------------------------------------------------------------------
+// mean over draws in numpy's summation order (np.mean(overall_ei, axis=1) on a
+// C-contiguous (M, H) array = 0.0 + pairwise_sum(row) then / H; numpy
+// loops_utils.h.src pairwise sum: <8 sequential, <=128 eight accumulators,
+// else split in halves rounded to multiples of 8).
+// ---------------------------------------------------------------------------
+__device__ double np_pairwise(const double* a, int64_t stride, int n)
+{
+#pragma clang fp contract(off)
+    if (n < 8) {
+        double res = -0.0;
+        for (int i = 0; i < n; ++i) res += a[i * stride];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = a[q * stride];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] += a[(i + q) * stride];
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i * stride];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, stride, n2) + np_pairwise(a + (int64_t)n2 * stride, stride, n - n2);
+}
+
+__global__ __launch_bounds__(256) void k_mean_over_draws(const double* __restrict__ ei_draw,
+                                                         double* __restrict__ ei_mean, int64_t M,
+                                                         int64_t Mp, int H)
+{
+#pragma clang fp contract(off)
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= M) return;
+    const double s = 0.0 + np_pairwise(ei_draw + c, Mp, H);
+    ei_mean[c] = s / (double)H;
+}
+
+void launch_mean_over_draws(hipStream_t s, const double* ei_draw, double* ei_mean, int64_t M,
+                            int64_t Mp, int H)
+{
+    hipLaunchKernelGGL(k_mean_over_draws, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s,
+                       ei_draw, ei_mean, M, Mp, H);
+}
+
+// ---------------------------------------------------------------------------
+// argmax with numpy semantics: the first NaN wins; otherwise the first maximum.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool better(double av, int64_t ai, double bv, int64_t bi)
+{
+    if (bi < 0) return ai >= 0;
+    if (ai < 0) return false;
+    const bool an = (av != av), bn = (bv != bv);
+    if (an || bn) {
+        if (an && bn) return ai < bi;
+        return an;
+    }
+    if (av > bv) return true;
+    if (av < bv) return false;
+    return ai < bi;
+}
+
+#define ARGMAX_BLOCKS 1024
+int argmax_blocks(int64_t M)
+{
+    int64_t b = (M + 255) / 256;
+    return (int)(b < ARGMAX_BLOCKS ? b : ARGMAX_BLOCKS);
+}
+
+__device__ __forceinline__ void block_argmax(double& v, int64_t& idx)
+{
+    __shared__ double sv[256];
+    __shared__ int64_t si[256];
+    sv[threadIdx.x] = v;
+    si[threadIdx.x] = idx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            if (better(sv[threadIdx.x + s], si[threadIdx.x + s], sv[threadIdx.x], si[threadIdx.x])) {
+                sv[threadIdx.x] = sv[threadIdx.x + s];
+                si[threadIdx.x] = si[threadIdx.x + s];
+            }
+        }
+        __syncthreads();
+    }
+    v = sv[0];
+    idx = si[0];
+}
+
+__global__ __launch_bounds__(256) void k_argmax_stage1(const double* __restrict__ v, int64_t M,
+                                                       double* __restrict__ bv, int64_t* __restrict__ bi)
+{
+    double best = 0.0;
+    int64_t besti = -1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const double x = v[i];
+        if (better(x, i, best, besti)) { best = x; besti = i; }
+    }
+    block_argmax(best, besti);
+    if (threadIdx.x == 0) { bv[blockIdx.x] = best; bi[blockIdx.x] = besti; }
+}
+
+__global__ __launch_bounds__(256) void k_argmax_stage2(const double* __restrict__ bv,
+                                                       const int64_t* __restrict__ bi, int nb,
+                                                       double* __restrict__ ov, int64_t* __restrict__ oi)
+{
+    double best = 0.0;
+    int64_t besti = -1;
+    for (int i = threadIdx.x; i < nb; i += 256)
+        if (better(bv[i], bi[i], best, besti)) { best = bv[i]; besti = bi[i]; }
+    block_argmax(best, besti);
+    if (threadIdx.x == 0) { *ov = best; *oi = besti; }
+}
+
+void launch_argmax(hipStream_t s, const double* v, int64_t M, double* blk_val, int64_t* blk_idx,
+                   double* out_val, int64_t* out_idx)
+{
+    const int nb = argmax_blocks(M);
+    hipLaunchKernelGGL(k_argmax_stage1, dim3(nb), dim3(256), 0, s, v, M, blk_val, blk_idx);
+    hipLaunchKernelGGL(k_argmax_stage2, dim3(1), dim3(256), 0, s, blk_val, blk_idx, nb, out_val, out_idx);
+}

@@ -1,0 +1,658 @@
+// libspx host side: handle, device buffers, kernel orchestration, C ABI (include/spx.h).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/spx.h"
+#include "common.h"
+
+#define SPX_VERSION 100
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(SPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SPX_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess)
+            return fail(SPX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return SPX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    double* d() const { return (double*)p; }
+};
+
+enum Stage {
+    ST_SCALE = 0, ST_COV_SELF, ST_CHOL_DIAG, ST_CHOL_PANEL, ST_TRINV, ST_GAMMA_ALPHA,
+    ST_COV_CROSS, ST_CROSS_MEAN, ST_PREDICT_GEMM, ST_EI_FINALIZE, ST_MEAN_ARGMAX,
+    ST_FACTOR_TOTAL, ST_EI_RUN_TOTAL, ST_COUNT
+};
+static const char* kStageNames[ST_COUNT] = {
+    "scale_rows", "cov_self", "chol_diag", "chol_panel", "trinv", "gamma_alpha",
+    "cov_cross", "cross_mean", "predict_gemm", "ei_finalize", "mean_argmax",
+    "factor_total", "ei_run_total"};
+
+struct spx_handle {
+    int device = 0;
+    bool inited = false;
+    hipStream_t stream = nullptr;
+
+    int64_t N = 0, M = 0, index_base = 0;
+    int D = 0, Dp = 0, Np = 0, H = 0;
+    bool have_obs = false, have_cand = false, have_hyp = false, have_time = false;
+    bool factored = false, ran = false, ran_moments = false;
+    int nmodels = 1;  // 1 = objective GP only, 2 = + log-duration GP
+    double best = 0.0;
+    int not_pd_draw = -1, not_pd_pivot = -1;
+    int64_t kst_budget = 128ll << 20;
+
+    std::vector<double> hyp_host, thyp_host;
+
+    DevBuf comp, vals, ldur, cand, hyp, htab;
+    DevBuf Xs, X2s, s1, Lm, WT, Dinv, gamma, alpha, info, lp;
+    DevBuf Cs, s2, Kst, part_ss, part_bg, time_m, ei_draw, ei_mean, mom_m, mom_v;
+    DevBuf am_val, am_idx, am_out_val, am_out_idx, scratch;
+
+    double best_val = 0.0;
+    int64_t best_idx = -1;
+
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int stage; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    double st_ms[ST_COUNT] = {0};
+    int64_t st_n[ST_COUNT] = {0};
+};
+
+static int ensure_init(spx_handle* h)
+{
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->inited) {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->inited = true;
+    }
+    return SPX_OK;
+}
+
+static int ev_begin(spx_handle* h, int stage)
+{
+    if (!h->timing) return -1;
+    if (h->ev_used == h->ev_pool.size()) {
+        spx_handle::Ev e;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return -1;
+        h->ev_pool.push_back(e);
+    }
+    spx_handle::Ev& e = h->ev_pool[h->ev_used];
+    e.stage = stage;
+    (void)hipEventRecord(e.a, h->stream);
+    return (int)h->ev_used++;
+}
+static void ev_end(spx_handle* h, int id)
+{
+    if (id >= 0) (void)hipEventRecord(h->ev_pool[id].b, h->stream);
+}
+static void ev_collect(spx_handle* h)
+{
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b) == hipSuccess) {
+            h->st_ms[h->ev_pool[i].stage] += ms;
+            h->st_n[h->ev_pool[i].stage] += 1;
+        }
+    }
+    h->ev_used = 0;
+}
+#define TIMED(stage, stmt)                 \
+    do {                                   \
+        int ev_ = ev_begin(h, stage);      \
+        stmt;                              \
+        ev_end(h, ev_);                    \
+    } while (0)
+
+static int padded_dim(int D)
+{
+    if (D <= 4) return 4;
+    if (D <= 8) return 8;
+    if (D <= 16) return 16;
+    return (int)round_up(D, 32);
+}
+
+extern "C" {
+
+int spx_version(void) { return SPX_VERSION; }
+const char* spx_last_error(void) { return g_err.c_str(); }
+
+int spx_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(SPX_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int spx_create(int device_id, spx_handle** out)
+{
+    if (!out || device_id < 0) return fail(SPX_ERR_ARG, "spx_create: bad arguments");
+    spx_handle* h = new spx_handle();
+    h->device = device_id;
+    *out = h;
+    return SPX_OK;
+}
+
+void spx_destroy(spx_handle* h)
+{
+    if (!h) return;
+    if (h->inited) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        DevBuf* bufs[] = {&h->comp, &h->vals, &h->ldur, &h->cand, &h->hyp, &h->htab, &h->Xs, &h->X2s,
+                          &h->s1, &h->Lm, &h->WT, &h->Dinv, &h->gamma, &h->alpha, &h->info, &h->lp,
+                          &h->Cs, &h->s2, &h->Kst, &h->part_ss, &h->part_bg, &h->time_m, &h->ei_draw,
+                          &h->ei_mean, &h->mom_m, &h->mom_v, &h->am_val, &h->am_idx, &h->am_out_val,
+                          &h->am_out_idx, &h->scratch};
+        for (DevBuf* b : bufs) b->release();
+        for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+int spx_set_option(spx_handle* h, const char* name, int64_t value)
+{
+    if (!h || !name) return fail(SPX_ERR_ARG, "spx_set_option: null");
+    if (!strcmp(name, "kstar_budget_bytes")) {
+        h->kst_budget = value > 0 ? value : (128ll << 20);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "timing")) {  // per-launch HIP events on the handle's stream; (re)starts the accumulators
+        h->timing = value != 0;
+        memset(h->st_ms, 0, sizeof h->st_ms);
+        memset(h->st_n, 0, sizeof h->st_n);
+        return SPX_OK;
+    }
+    return fail(SPX_ERR_ARG, "spx_set_option: unknown option '%s'", name);
+}
+
+int spx_set_observations(spx_handle* h, const double* comp, const double* vals, int64_t N, int32_t D)
+{
+    if (!h || !comp || !vals || N < 1 || D < 1 || N > (1 << 20))
+        return fail(SPX_ERR_ARG, "spx_set_observations: bad arguments (N=%lld, D=%d)", (long long)N, D);
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    if (h->have_cand && D != h->D) h->have_cand = false;
+    if (h->have_hyp && D != h->D) { h->have_hyp = false; h->have_time = false; }
+    h->N = N; h->D = D; h->Dp = padded_dim(D); h->Np = (int)round_up(N, SPX_PADN);
+    if ((rc = h->comp.reserve((size_t)N * D * 8))) return rc;
+    if ((rc = h->vals.reserve((size_t)N * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(h->comp.p, comp, (size_t)N * D * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->vals.p, vals, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    double b = vals[0];
+    for (int64_t i = 1; i < N; ++i) {  // np.min semantics: NaN propagates
+        if (vals[i] != vals[i]) { b = vals[i]; break; }
+        if (vals[i] < b) b = vals[i];
+    }
+    h->best = b;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_obs = true; h->have_time = false; h->factored = false; h->ran = false;
+    return SPX_OK;
+}
+
+int spx_set_candidates(spx_handle* h, const double* cand, int64_t M, int32_t D, int64_t index_base)
+{
+    if (!h || !cand || M < 1 || D < 1)
+        return fail(SPX_ERR_ARG, "spx_set_candidates: bad arguments (M=%lld, D=%d)", (long long)M, D);
+    if (h->have_obs && D != h->D)
+        return fail(SPX_ERR_ARG, "spx_set_candidates: D=%d but observations have D=%d", D, h->D);
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    if (!h->have_obs) { h->D = D; h->Dp = padded_dim(D); }
+    h->M = M; h->index_base = index_base;
+    if ((rc = h->cand.reserve((size_t)M * D * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(h->cand.p, cand, (size_t)M * D * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_cand = true; h->ran = false;
+    return SPX_OK;
+}
+
+int spx_set_hypers(spx_handle* h, const double* hypers, int32_t H)
+{
+    if (!h || !hypers || H < 1) return fail(SPX_ERR_ARG, "spx_set_hypers: bad arguments (H=%d)", H);
+    if (!h->have_obs) return fail(SPX_ERR_ARG, "spx_set_hypers: call spx_set_observations first");
+    h->H = H;
+    h->hyp_host.assign(hypers, hypers + (size_t)H * (3 + h->D));
+    h->have_hyp = true; h->have_time = false; h->factored = false; h->ran = false;
+    return SPX_OK;
+}
+
+int spx_set_time_model(spx_handle* h, const double* log_durs, const double* time_hypers)
+{
+    if (!h) return fail(SPX_ERR_ARG, "spx_set_time_model: null handle");
+    if (!log_durs || !time_hypers) { h->have_time = false; h->factored = false; return SPX_OK; }
+    if (!h->have_obs || !h->have_hyp)
+        return fail(SPX_ERR_ARG, "spx_set_time_model: set observations and hypers first");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    if ((rc = h->ldur.reserve((size_t)h->N * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(h->ldur.p, log_durs, (size_t)h->N * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->thyp_host.assign(time_hypers, time_hypers + (size_t)h->H * (3 + h->D));
+    h->have_time = true; h->factored = false; h->ran = false;
+    return SPX_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int do_factor(spx_handle* h, bool tolerate_not_pd)
+{
+    if (!h->have_obs || !h->have_hyp)
+        return fail(SPX_ERR_ARG, "spx_factor: observations and hypers must be set first");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int nm = h->have_time ? 2 : 1;
+    h->nmodels = nm;
+    const int H = h->H, nh = nm * H, D = h->D, Dp = h->Dp, Np = h->Np;
+    const int64_t N = h->N;
+    const int nblk = Np / SPX_NB;
+    const int hs = 3 + D;
+
+    // host-side hyper tables: raw rows (for ls) and [mean, noise, amp2, amp2*(1+1e-6)]
+    std::vector<double> raw((size_t)nh * hs), tab((size_t)nh * SPX_HT);
+    for (int m = 0; m < nm; ++m) {
+        const std::vector<double>& src = m ? h->thyp_host : h->hyp_host;
+        for (int i = 0; i < H; ++i) {
+            const double* r = &src[(size_t)i * hs];
+            memcpy(&raw[((size_t)m * H + i) * hs], r, sizeof(double) * hs);
+            double* t = &tab[((size_t)m * H + i) * SPX_HT];
+            t[0] = r[0]; t[1] = r[1]; t[2] = r[2];
+            t[3] = r[2] * (1 + 1e-6);  // self.amp2*(1+1e-6), GPEIChooser.py:199
+        }
+    }
+    if ((rc = h->hyp.reserve(raw.size() * 8))) return rc;
+    if ((rc = h->htab.reserve(tab.size() * 8))) return rc;
+    const size_t nn = (size_t)nh * Np * Np;
+    if ((rc = h->Xs.reserve((size_t)nh * Np * Dp * 8))) return rc;
+    if ((rc = h->X2s.reserve((size_t)nh * Np * Dp * 8))) return rc;
+    if ((rc = h->s1.reserve((size_t)nh * Np * 8))) return rc;
+    if ((rc = h->Lm.reserve(nn * 8))) return rc;
+    if ((rc = h->WT.reserve(nn * 8))) return rc;
+    if ((rc = h->Dinv.reserve((size_t)nh * nblk * SPX_NB * SPX_NB * 8))) return rc;
+    if ((rc = h->gamma.reserve((size_t)nh * Np * 8))) return rc;
+    if ((rc = h->alpha.reserve((size_t)nh * Np * 8))) return rc;
+    if ((rc = h->info.reserve((size_t)nh * sizeof(int)))) return rc;
+
+    hipStream_t s = h->stream;
+    h->ev_used = 0;
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0));
+    HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipMemcpyAsync(h->hyp.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->htab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(t0, s));
+    HIPCHK(hipMemsetAsync(h->info.p, 0, (size_t)nh * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(h->WT.p, 0, nn * 8, s));
+
+    const double* ls = h->hyp.d() + 3;
+    TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d()));
+    // second operand pre-multiplied by 2 (gp.py:50); the row norms it writes are identical
+    TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 2.0, h->X2s.d(), h->s1.d()));
+    TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh));
+    for (int k = 0; k < nblk; ++k) {
+        TIMED(ST_CHOL_DIAG, launch_chol_diag(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, Np, k, nh));
+        if (k + 1 < nblk) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh));
+    }
+    TIMED(ST_TRINV, launch_trinv(s, h->Lm.d(), h->Dinv.d(), h->WT.d(), Np, nh));
+    TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d(), h->vals.d(), h->htab.d(), h->gamma.d(), (int)N, Np, H));
+    if (nm == 2)
+        TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d() + (size_t)H * Np * Np, h->ldur.d(),
+                                            h->htab.d() + (size_t)H * SPX_HT,
+                                            h->gamma.d() + (size_t)H * Np, (int)N, Np, H));
+    TIMED(ST_GAMMA_ALPHA, launch_alpha(s, h->WT.d(), h->gamma.d(), h->alpha.d(), Np, nh));
+    HIPCHK(hipEventRecord(t1, s));
+    std::vector<int> info(nh);
+    HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)nh * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (h->timing) {
+        ev_collect(h);
+        h->st_ms[ST_FACTOR_TOTAL] += ms; h->st_n[ST_FACTOR_TOTAL] += 1;
+    }
+    h->not_pd_draw = h->not_pd_pivot = -1;
+    for (int i = 0; i < nh; ++i)
+        if (info[i]) { h->not_pd_draw = i; h->not_pd_pivot = info[i] - 1; break; }
+    h->factored = true;
+    h->ran = false;
+    if (h->not_pd_draw >= 0 && !tolerate_not_pd) {
+        h->factored = false;
+        return fail(SPX_ERR_NOT_PD, "%d-th leading minor of the array is not positive definite (draw %d%s)",
+                    h->not_pd_pivot + 1, h->not_pd_draw % H, h->not_pd_draw >= H ? ", time model" : "");
+    }
+    return SPX_OK;
+}
+
+int spx_factor(spx_handle* h)
+{
+    if (!h) return fail(SPX_ERR_ARG, "spx_factor: null handle");
+    return do_factor(h, false);
+}
+
+int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot)
+{
+    if (!h) return fail(SPX_ERR_ARG, "null handle");
+    if (draw) *draw = h->not_pd_draw;
+    if (pivot) *pivot = h->not_pd_pivot;
+    return SPX_OK;
+}
+
+// candidate-chunk / draw-group plan for the K(X*,X) staging buffer
+static void plan_chunks(const spx_handle* h, int64_t* Mc, int* Hb)
+{
+    const int64_t Mp = round_up(h->M, SPX_BN);
+    int64_t mc = h->kst_budget / (8ll * h->Np);
+    mc = mc / SPX_BN * SPX_BN;
+    if (mc < SPX_BN) mc = SPX_BN;
+    if (mc > Mp) mc = Mp;
+    int64_t hb = h->kst_budget / (8ll * h->Np * mc);
+    if (hb < 1) hb = 1;
+    if (hb > h->H) hb = h->H;
+    *Mc = mc;
+    *Hb = (int)hb;
+}
+
+int spx_ei_run(spx_handle* h, int32_t flags)
+{
+    if (!h) return fail(SPX_ERR_ARG, "spx_ei_run: null handle");
+    if (!h->factored) return fail(SPX_ERR_ARG, "spx_ei_run: call spx_factor first");
+    if (!h->have_cand) return fail(SPX_ERR_ARG, "spx_ei_run: no candidates set");
+    const bool per_sec = (flags & SPX_FLAG_PER_SEC) != 0;
+    const bool keep_mom = (flags & SPX_FLAG_KEEP_MOMENTS) != 0;
+    if (per_sec && h->nmodels != 2)
+        return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_PER_SEC needs spx_set_time_model before spx_factor");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int H = h->H, D = h->D, Dp = h->Dp, Np = h->Np, hs = 3 + D;
+    const int64_t N = h->N, M = h->M, Mp = round_up(M, SPX_BN);
+    const int nrb = Np / SPX_BM;
+    int64_t Mc; int Hb;
+    plan_chunks(h, &Mc, &Hb);
+
+    if ((rc = h->Cs.reserve((size_t)Hb * Mc * Dp * 8))) return rc;
+    if ((rc = h->s2.reserve((size_t)Hb * Mc * 8))) return rc;
+    if ((rc = h->Kst.reserve((size_t)Hb * Np * Mc * 8))) return rc;
+    if ((rc = h->part_ss.reserve((size_t)nrb * Hb * Mc * 8))) return rc;
+    if ((rc = h->part_bg.reserve((size_t)nrb * Hb * Mc * 8))) return rc;
+    if ((rc = h->ei_draw.reserve((size_t)H * Mp * 8))) return rc;
+    if ((rc = h->ei_mean.reserve((size_t)Mp * 8))) return rc;
+    if (per_sec && (rc = h->time_m.reserve((size_t)Hb * Mc * 8))) return rc;
+    if (keep_mom) {
+        if ((rc = h->mom_m.reserve((size_t)H * Mp * 8))) return rc;
+        if ((rc = h->mom_v.reserve((size_t)H * Mp * 8))) return rc;
+    }
+    const int nab = argmax_blocks(M);
+    if ((rc = h->am_val.reserve((size_t)nab * 8))) return rc;
+    if ((rc = h->am_idx.reserve((size_t)nab * 8))) return rc;
+    if ((rc = h->am_out_val.reserve(8))) return rc;
+    if ((rc = h->am_out_idx.reserve(8))) return rc;
+
+    hipStream_t s = h->stream;
+    if (flags & SPX_FLAG_TIMING) h->timing = true;
+    h->ev_used = 0;
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0));
+    HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, s));
+
+    const double* ls = h->hyp.d() + 3;
+    const size_t nn = (size_t)Np * Np;
+    for (int64_t c0 = 0; c0 < Mp; c0 += Mc) {
+        const int mc = (int)std::min<int64_t>(Mc, Mp - c0);       // multiple of 128
+        const int64_t nreal = std::min<int64_t>(mc, M - c0);      // real candidates in the chunk
+        const double* xc = h->cand.d() + (size_t)c0 * D;
+        for (int h0 = 0; h0 < H; h0 += Hb) {
+            const int nhb = std::min(Hb, H - h0);
+            if (per_sec) {
+                const int t0i = H + h0;
+                TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls + (size_t)t0i * hs, hs, nhb, 2.0,
+                                                  h->Cs.d(), h->s2.d()));
+                TIMED(ST_CROSS_MEAN, launch_cross_mean(s, h->Xs.d() + (size_t)t0i * Np * Dp, h->s1.d() + (size_t)t0i * Np,
+                                                       h->Cs.d(), h->s2.d(), h->htab.d() + (size_t)t0i * SPX_HT,
+                                                       h->alpha.d() + (size_t)t0i * Np, h->time_m.d(), (int)N, Np, mc, Dp, nhb));
+            }
+            TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls + (size_t)h0 * hs, hs, nhb, 2.0,
+                                              h->Cs.d(), h->s2.d()));
+            TIMED(ST_COV_CROSS, launch_cov_cross(s, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
+                                                 h->Cs.d(), h->s2.d(), h->htab.d() + (size_t)h0 * SPX_HT,
+                                                 h->Kst.d(), (int)N, Np, mc, Dp, nhb));
+            TIMED(ST_PREDICT_GEMM, launch_predict_gemm(s, h->WT.d() + (size_t)h0 * nn, h->Kst.d(),
+                                                       h->gamma.d() + (size_t)h0 * Np, h->part_ss.d(), h->part_bg.d(),
+                                                       Np, mc, nhb));
+            TIMED(ST_EI_FINALIZE, launch_ei_finalize(s, h->part_ss.d(), h->part_bg.d(), h->htab.d() + (size_t)h0 * SPX_HT,
+                                                     per_sec ? h->time_m.d() : nullptr, h->best, h->ei_draw.d(),
+                                                     keep_mom ? h->mom_m.d() : nullptr, keep_mom ? h->mom_v.d() : nullptr,
+                                                     nrb, mc, nhb, c0, M, Mp, h0));
+        }
+    }
+    TIMED(ST_MEAN_ARGMAX, {
+        launch_mean_over_draws(s, h->ei_draw.d(), h->ei_mean.d(), M, Mp, H);
+        launch_argmax(s, h->ei_mean.d(), M, h->am_val.d(), (int64_t*)h->am_idx.p, h->am_out_val.d(),
+                      (int64_t*)h->am_out_idx.p);
+    });
+    HIPCHK(hipEventRecord(t1, s));
+    HIPCHK(hipMemcpyAsync(&h->best_val, h->am_out_val.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&h->best_idx, h->am_out_idx.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (h->timing) {
+        ev_collect(h);
+        h->st_ms[ST_EI_RUN_TOTAL] += ms; h->st_n[ST_EI_RUN_TOTAL] += 1;
+    }
+    h->ran = true;
+    h->ran_moments = keep_mom;
+    return SPX_OK;
+}
+
+int spx_get_best(spx_handle* h, int64_t* best_idx, double* best_val)
+{
+    if (!h || !h->ran) return fail(SPX_ERR_ARG, "spx_get_best: no results (call spx_ei_run)");
+    if (best_idx) *best_idx = h->best_idx + h->index_base;
+    if (best_val) *best_val = h->best_val;
+    return SPX_OK;
+}
+
+int spx_get_ei_mean(spx_handle* h, double* out)
+{
+    if (!h || !out || !h->ran) return fail(SPX_ERR_ARG, "spx_get_ei_mean: no results / null output");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, h->ei_mean.p, (size_t)h->M * 8, hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
+int spx_get_ei_draws(spx_handle* h, double* out)
+{
+    if (!h || !out || !h->ran) return fail(SPX_ERR_ARG, "spx_get_ei_draws: no results / null output");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int64_t M = h->M, Mp = round_up(M, SPX_BN);
+    const int H = h->H;
+    std::vector<double> tmp((size_t)H * Mp);
+    HIPCHK(hipMemcpy(tmp.data(), h->ei_draw.p, tmp.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < M; ++c)
+        for (int d = 0; d < H; ++d) out[(size_t)c * H + d] = tmp[(size_t)d * Mp + c];
+    return SPX_OK;
+}
+
+int spx_get_moments(spx_handle* h, int32_t draw, double* func_m, double* func_v)
+{
+    if (!h || !h->ran || !h->ran_moments)
+        return fail(SPX_ERR_ARG, "spx_get_moments: run spx_ei_run with SPX_FLAG_KEEP_MOMENTS first");
+    if (draw < 0 || draw >= h->H) return fail(SPX_ERR_ARG, "spx_get_moments: draw out of range");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int64_t Mp = round_up(h->M, SPX_BN);
+    if (func_m) HIPCHK(hipMemcpy(func_m, h->mom_m.d() + (size_t)draw * Mp, (size_t)h->M * 8, hipMemcpyDeviceToHost));
+    if (func_v) HIPCHK(hipMemcpy(func_v, h->mom_v.d() + (size_t)draw * Mp, (size_t)h->M * 8, hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
+int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* alpha)
+{
+    if (!h || !h->factored) return fail(SPX_ERR_ARG, "spx_get_factor: call spx_factor first");
+    const int nh = h->nmodels * h->H;
+    if (draw < 0 || draw >= nh) return fail(SPX_ERR_ARG, "spx_get_factor: draw out of range");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int Np = h->Np, Dp = h->Dp;
+    const int64_t N = h->N;
+    const size_t nn = (size_t)Np * Np;
+    if (K) {
+        if ((rc = h->scratch.reserve(nn * 8))) return rc;
+        launch_cov_self(h->stream, h->Xs.d() + (size_t)draw * Np * Dp, h->s1.d() + (size_t)draw * Np,
+                        h->X2s.d() + (size_t)draw * Np * Dp, h->htab.d() + (size_t)draw * SPX_HT,
+                        h->scratch.d(), (int)N, Np, Dp, 1);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy2D(K, (size_t)N * 8, h->scratch.p, (size_t)Np * 8, (size_t)N * 8, (size_t)N, hipMemcpyDeviceToHost));
+    }
+    if (L) {
+        HIPCHK(hipMemcpy2D(L, (size_t)N * 8, h->Lm.d() + (size_t)draw * nn, (size_t)Np * 8, (size_t)N * 8, (size_t)N,
+                           hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = i + 1; j < N; ++j) L[i * N + j] = 0.0;
+    }
+    if (alpha) HIPCHK(hipMemcpy(alpha, h->alpha.d() + (size_t)draw * Np, (size_t)N * 8, hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
+int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, double* out)
+{
+    if (!h || !out || !h->factored || !h->have_cand)
+        return fail(SPX_ERR_ARG, "spx_get_cross_cov: need spx_factor and candidates");
+    const int nh = h->nmodels * h->H;
+    if (draw < 0 || draw >= nh || c0 < 0 || nc < 1 || c0 + nc > h->M)
+        return fail(SPX_ERR_ARG, "spx_get_cross_cov: range error");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int Np = h->Np, Dp = h->Dp, D = h->D, hs = 3 + D;
+    const int mc = (int)round_up(nc, SPX_BN);
+    DevBuf cs, s2, kst;
+    if ((rc = cs.reserve((size_t)mc * Dp * 8)) || (rc = s2.reserve((size_t)mc * 8)) ||
+        (rc = kst.reserve((size_t)Np * mc * 8))) {
+        cs.release(); s2.release(); kst.release();
+        return rc;
+    }
+    hipStream_t s = h->stream;
+    launch_scale_rows(s, h->cand.d() + (size_t)c0 * D, nc, mc, D, Dp, h->hyp.d() + 3 + (size_t)draw * hs, hs, 1, 2.0,
+                      cs.d(), s2.d());
+    launch_cov_cross(s, h->Xs.d() + (size_t)draw * Np * Dp, h->s1.d() + (size_t)draw * Np, cs.d(), s2.d(),
+                     h->htab.d() + (size_t)draw * SPX_HT, kst.d(), (int)h->N, Np, mc, Dp, 1);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess)
+        e = hipMemcpy2D(out, (size_t)nc * 8, kst.p, (size_t)mc * 8, (size_t)nc * 8, (size_t)h->N, hipMemcpyDeviceToHost);
+    cs.release(); s2.release(); kst.release();
+    if (e != hipSuccess) return fail(SPX_ERR_HIP, "spx_get_cross_cov: %s", hipGetErrorString(e));
+    return SPX_OK;
+}
+
+int spx_gp_logprob(spx_handle* h, double* out)
+{
+    if (!h || !out) return fail(SPX_ERR_ARG, "spx_gp_logprob: null");
+    const bool had_time = h->have_time;
+    h->have_time = false;  // data term of the objective GP only
+    int rc = do_factor(h, true);
+    h->have_time = had_time;
+    if (rc) return rc;
+    if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
+    launch_logprob(h->stream, h->Lm.d(), h->gamma.d(), (const int*)h->info.p, h->lp.d(), h->Np, h->H);
+    HIPCHK(hipMemcpyAsync(out, h->lp.p, (size_t)h->H * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->not_pd_draw >= 0 || had_time) h->factored = false;  // force a clean spx_factor before EI
+    return SPX_OK;
+}
+
+static int run_grid(spx_handle* h, const double* comp, const double* vals, const double* log_durs,
+                    int64_t N, int32_t D, const double* cand, int64_t M, const double* hypers,
+                    const double* time_hypers, int32_t H, int32_t flags, double* ei_mean_out,
+                    double* ei_draw_out, int64_t* best_idx, double* best_val)
+{
+    int rc;
+    if ((rc = spx_set_observations(h, comp, vals, N, D))) return rc;
+    if ((rc = spx_set_candidates(h, cand, M, D, 0))) return rc;
+    if ((rc = spx_set_hypers(h, hypers, H))) return rc;
+    if (log_durs && (rc = spx_set_time_model(h, log_durs, time_hypers))) return rc;
+    if ((rc = spx_factor(h))) return rc;
+    if ((rc = spx_ei_run(h, flags))) return rc;
+    if ((rc = spx_get_best(h, best_idx, best_val))) return rc;
+    if (ei_mean_out && (rc = spx_get_ei_mean(h, ei_mean_out))) return rc;
+    if (ei_draw_out && (rc = spx_get_ei_draws(h, ei_draw_out))) return rc;
+    return SPX_OK;
+}
+
+int spx_ei_grid(spx_handle* h, const double* comp, const double* vals, int64_t N, int32_t D,
+                const double* cand, int64_t M, const double* hypers, int32_t H, int32_t flags,
+                double* ei_mean_out, double* ei_draw_out, int64_t* best_idx, double* best_val)
+{
+    if (!h) return fail(SPX_ERR_ARG, "spx_ei_grid: null handle");
+    return run_grid(h, comp, vals, nullptr, N, D, cand, M, hypers, nullptr, H, flags & ~SPX_FLAG_PER_SEC,
+                    ei_mean_out, ei_draw_out, best_idx, best_val);
+}
+
+int spx_ei_per_sec_grid(spx_handle* h, const double* comp, const double* vals, const double* log_durs,
+                        int64_t N, int32_t D, const double* cand, int64_t M, const double* hypers,
+                        const double* time_hypers, int32_t H, int32_t flags, double* ei_mean_out,
+                        double* ei_draw_out, int64_t* best_idx, double* best_val)
+{
+    if (!h || !log_durs || !time_hypers) return fail(SPX_ERR_ARG, "spx_ei_per_sec_grid: null argument");
+    return run_grid(h, comp, vals, log_durs, N, D, cand, M, hypers, time_hypers, H, flags | SPX_FLAG_PER_SEC,
+                    ei_mean_out, ei_draw_out, best_idx, best_val);
+}
+
+int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n)
+{
+    if (!h) return fail(SPX_ERR_ARG, "null handle");
+    for (int i = 0; i < n && i < ST_COUNT; ++i) {
+        if (ms) ms[i] = h->st_ms[i];
+        if (launches) launches[i] = h->st_n[i];
+    }
+    return ST_COUNT;
+}
+
+const char* spx_timing_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+}  // extern "C"

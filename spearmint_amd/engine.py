@@ -1,0 +1,295 @@
+"""ctypes binding of libspx.so (include/spx.h) -- the only way the Python side
+reaches the GPU.  There is NO CPU fallback: if the shared library or a HIP
+device is missing, construction / the first call raises.
+
+Written in the Python 2/3 common subset so the chooser modules can be dropped
+into a Python-2 Spearmint checkout.
+"""
+from __future__ import print_function
+
+import ctypes
+import os
+
+import numpy as np
+
+try:
+    from numpy.linalg import LinAlgError
+except ImportError:  # pragma: no cover
+    LinAlgError = ArithmeticError
+
+SPX_OK = 0
+SPX_ERR_ARG = -1
+SPX_ERR_HIP = -2
+SPX_ERR_NOT_PD = -3
+
+FLAG_PER_SEC = 1
+FLAG_KEEP_MOMENTS = 2
+FLAG_TIMING = 4
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+_c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+# every symbol include/spx.h declares: name -> (restype, argtypes)
+_vp = ctypes.c_void_p
+ABI = {
+    "spx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "spx_destroy": (None, [_vp]),
+    "spx_last_error": (ctypes.c_char_p, []),
+    "spx_version": (ctypes.c_int, []),
+    "spx_device_count": (ctypes.c_int, []),
+    "spx_set_observations": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int32]),
+    "spx_set_candidates": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64]),
+    "spx_set_hypers": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int32]),
+    "spx_set_time_model": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
+    "spx_factor": (ctypes.c_int, [_vp]),
+    "spx_ei_run": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "spx_get_best": (ctypes.c_int, [_vp, _c_int64_p, _c_double_p]),
+    "spx_get_ei_mean": (ctypes.c_int, [_vp, _c_double_p]),
+    "spx_get_ei_draws": (ctypes.c_int, [_vp, _c_double_p]),
+    "spx_ei_grid": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int32,
+                                   _c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_int32,
+                                   ctypes.c_int32, _c_double_p, _c_double_p, _c_int64_p, _c_double_p]),
+    "spx_ei_per_sec_grid": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int64,
+                                           ctypes.c_int32, _c_double_p, ctypes.c_int64, _c_double_p,
+                                           _c_double_p, ctypes.c_int32, ctypes.c_int32, _c_double_p,
+                                           _c_double_p, _c_int64_p, _c_double_p]),
+    "spx_get_factor": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    "spx_get_cross_cov": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
+    "spx_get_moments": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p, _c_double_p]),
+    "spx_gp_logprob": (ctypes.c_int, [_vp, _c_double_p]),
+    "spx_not_pd_info": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p]),
+    "spx_get_timings": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p, ctypes.c_int]),
+    "spx_timing_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "spx_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+}
+
+_lib = None
+
+
+def default_lib_path():
+    return os.environ.get("SPX_LIB") or os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), "libspx.so")
+
+
+def load_library(path=None):
+    """dlopen libspx.so and declare every prototype.  Raises OSError when the
+    library has not been built (run `python -c "import __graft_entry__ as g; g.build()"`
+    or `make -C spearmint_amd/csrc`)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or default_lib_path()
+    if not os.path.exists(p):
+        raise OSError("libspx.so not found at %s -- build it with `make -C spearmint_amd/csrc` "
+                      "(there is no CPU fallback)" % p)
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p) if a is not None else None
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class SpxError(RuntimeError):
+    pass
+
+
+class Engine(object):
+    """One GPU, one handle.  Mirrors the resident-data C API.
+
+    Typical use (what the choosers do, GPEIOptChooser.py:331-341 + :294):
+
+        eng = Engine(device=0)
+        best, ei_mean, overall_ei = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    """
+
+    def __init__(self, device=0, lib=None):
+        self._lib = load_library(lib)
+        self._h = _vp()
+        self._check(self._lib.spx_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+        self.N = self.M = self.D = self.H = 0
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc):
+        if rc == SPX_OK:
+            return
+        msg = self._lib.spx_last_error()
+        msg = msg.decode("utf-8", "replace") if isinstance(msg, bytes) else str(msg)
+        if rc == SPX_ERR_NOT_PD:
+            raise LinAlgError(msg)  # what spla.cholesky raises in the reference
+        if rc == SPX_ERR_ARG:
+            raise ValueError(msg)
+        raise SpxError(msg)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.spx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __getstate__(self):
+        raise TypeError("Engine holds a GPU context and cannot be pickled; choosers drop it in __getstate__")
+
+    # -- resident data ----------------------------------------------------
+    def set_observations(self, comp, vals):
+        comp = _f64(comp)
+        vals = _f64(vals).ravel()
+        if comp.ndim != 2 or comp.shape[0] != vals.shape[0]:
+            raise ValueError("comp must be (N, D) and vals (N,)")
+        self.N, self.D = comp.shape
+        self._check(self._lib.spx_set_observations(self._h, _dp(comp), _dp(vals), self.N, self.D))
+
+    def set_candidates(self, cand, index_base=0):
+        cand = _f64(cand)
+        if cand.ndim != 2:
+            raise ValueError("cand must be (M, D)")
+        self.M = cand.shape[0]
+        self._check(self._lib.spx_set_candidates(self._h, _dp(cand), self.M, cand.shape[1], int(index_base)))
+
+    def set_hypers(self, hypers):
+        hypers = _f64(np.atleast_2d(hypers))
+        if hypers.shape[1] != 3 + self.D:
+            raise ValueError("hypers must be (H, 3 + D) rows [mean, noise, amp2, ls...]")
+        self.H = hypers.shape[0]
+        self._check(self._lib.spx_set_hypers(self._h, _dp(hypers), self.H))
+
+    def set_time_model(self, log_durs, time_hypers):
+        if log_durs is None:
+            self._check(self._lib.spx_set_time_model(self._h, None, None))
+            return
+        log_durs = _f64(log_durs).ravel()
+        time_hypers = _f64(np.atleast_2d(time_hypers))
+        if log_durs.shape[0] != self.N or time_hypers.shape != (self.H, 3 + self.D):
+            raise ValueError("log_durs must be (N,), time_hypers (H, 3 + D)")
+        self._check(self._lib.spx_set_time_model(self._h, _dp(log_durs), _dp(time_hypers)))
+
+    def set_option(self, name, value):
+        self._check(self._lib.spx_set_option(self._h, name.encode("ascii"), int(value)))
+
+    # -- hot path ---------------------------------------------------------
+    def factor(self):
+        self._check(self._lib.spx_factor(self._h))
+
+    def ei_run(self, flags=0):
+        self._check(self._lib.spx_ei_run(self._h, int(flags)))
+
+    def best(self):
+        idx = ctypes.c_int64(-1)
+        val = ctypes.c_double(0.0)
+        self._check(self._lib.spx_get_best(self._h, ctypes.byref(idx), ctypes.byref(val)))
+        return int(idx.value), float(val.value)
+
+    def ei_mean(self):
+        out = np.empty(self.M)
+        self._check(self._lib.spx_get_ei_mean(self._h, _dp(out)))
+        return out
+
+    def ei_draws(self):
+        out = np.empty((self.M, self.H))
+        self._check(self._lib.spx_get_ei_draws(self._h, _dp(out)))
+        return out
+
+    # -- one-shot (host buffers in, results out) ---------------------------
+    def ei_grid(self, comp, vals, cand, hypers, want_mean=True, want_draws=False, flags=0):
+        """(best_index, best_value, ei_mean or None, overall_ei[M,H] or None)"""
+        comp = _f64(comp); vals = _f64(vals).ravel(); cand = _f64(cand)
+        hypers = _f64(np.atleast_2d(hypers))
+        N, D = comp.shape
+        M, H = cand.shape[0], hypers.shape[0]
+        if hypers.shape[1] != 3 + D or cand.shape[1] != D or vals.shape[0] != N:
+            raise ValueError("shape mismatch")
+        mean = np.empty(M) if want_mean else None
+        draws = np.empty((M, H)) if want_draws else None
+        idx = ctypes.c_int64(-1); val = ctypes.c_double(0.0)
+        self._check(self._lib.spx_ei_grid(self._h, _dp(comp), _dp(vals), N, D, _dp(cand), M, _dp(hypers),
+                                          H, int(flags), _dp(mean), _dp(draws),
+                                          ctypes.byref(idx), ctypes.byref(val)))
+        self.N, self.D, self.M, self.H = N, D, M, H
+        return int(idx.value), float(val.value), mean, draws
+
+    def ei_per_sec_grid(self, comp, vals, log_durs, cand, hypers, time_hypers,
+                        want_mean=True, want_draws=False, flags=0):
+        comp = _f64(comp); vals = _f64(vals).ravel(); cand = _f64(cand)
+        log_durs = _f64(log_durs).ravel()
+        hypers = _f64(np.atleast_2d(hypers)); time_hypers = _f64(np.atleast_2d(time_hypers))
+        N, D = comp.shape
+        M, H = cand.shape[0], hypers.shape[0]
+        if (hypers.shape[1] != 3 + D or time_hypers.shape != hypers.shape or cand.shape[1] != D
+                or vals.shape[0] != N or log_durs.shape[0] != N):
+            raise ValueError("shape mismatch")
+        mean = np.empty(M) if want_mean else None
+        draws = np.empty((M, H)) if want_draws else None
+        idx = ctypes.c_int64(-1); val = ctypes.c_double(0.0)
+        self._check(self._lib.spx_ei_per_sec_grid(self._h, _dp(comp), _dp(vals), _dp(log_durs), N, D,
+                                                  _dp(cand), M, _dp(hypers), _dp(time_hypers), H,
+                                                  int(flags), _dp(mean), _dp(draws),
+                                                  ctypes.byref(idx), ctypes.byref(val)))
+        self.N, self.D, self.M, self.H = N, D, M, H
+        return int(idx.value), float(val.value), mean, draws
+
+    # -- building blocks ---------------------------------------------------
+    def get_factor(self, draw, want_K=True, want_L=True, want_alpha=True):
+        N = self.N
+        K = np.empty((N, N)) if want_K else None
+        L = np.empty((N, N)) if want_L else None
+        a = np.empty(N) if want_alpha else None
+        self._check(self._lib.spx_get_factor(self._h, int(draw), _dp(K), _dp(L), _dp(a)))
+        return K, L, a
+
+    def get_cross_cov(self, draw, c0=0, nc=None):
+        nc = self.M - c0 if nc is None else nc
+        out = np.empty((self.N, nc))
+        self._check(self._lib.spx_get_cross_cov(self._h, int(draw), int(c0), int(nc), _dp(out)))
+        return out
+
+    def get_moments(self, draw):
+        m = np.empty(self.M); v = np.empty(self.M)
+        self._check(self._lib.spx_get_moments(self._h, int(draw), _dp(m), _dp(v)))
+        return m, v
+
+    def gp_logprob(self):
+        out = np.empty(self.H)
+        self._check(self._lib.spx_gp_logprob(self._h, _dp(out)))
+        return out
+
+    def not_pd_info(self):
+        d = ctypes.c_int32(-1); p = ctypes.c_int32(-1)
+        self._check(self._lib.spx_not_pd_info(self._h, ctypes.byref(d), ctypes.byref(p)))
+        return int(d.value), int(p.value)
+
+    def timings(self):
+        """{stage: (ms_total, launches)} accumulated since set_option('timing', 1)."""
+        n = self._lib.spx_get_timings(self._h, None, None, 0)
+        ms = (ctypes.c_double * n)(); cnt = (ctypes.c_int64 * n)()
+        self._lib.spx_get_timings(self._h, ms, cnt, n)
+        out = {}
+        for i in range(n):
+            name = self._lib.spx_timing_name(i)
+            name = name.decode("ascii") if isinstance(name, bytes) else name
+            out[name] = (float(ms[i]), int(cnt[i]))
+        return out
+
+
+def device_count(lib=None):
+    n = load_library(lib).spx_device_count()
+    return n if n > 0 else 0
