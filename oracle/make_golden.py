@@ -20,6 +20,8 @@ Fixtures (all float64, ref = the reference's own functions):
                    (sobol_lib.i4_sobol_generate(2,1000,1).T), Branin values on
                    the first 20 points, a seeded GPEIChooser.next() call: the
                    slice-sampled hypers of each draw, overall_ei, chosen index.
+  chooser_next.npz the reference's GPEIOptChooser.next / GPEIperSecChooser.next on Branin
+                   (seeded; burnin + MCMC + refinement), the point they propose.
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
 """
 import os
@@ -176,6 +178,60 @@ def gen_branin_c1(mods, tmp):
                         job=int(job), seed=seed)
 
 
+def _branin_inputs(mods, n_done=20, G=1000):
+    sob = mods["sobol_lib"]
+    grid = np.transpose(sob.i4_sobol_generate(2, G, 1))
+    values = np.zeros(G) + np.nan
+    durations = np.zeros(G) + np.nan
+    status = np.zeros(G, dtype=int)
+    for i in range(n_done):
+        values[i] = branin(grid[i, 0], grid[i, 1])
+        durations[i] = 1.0 + 3.0 * grid[i, 0] + np.sin(5 * grid[i, 1]) ** 2   # synthetic run times (s)
+        status[i] = 2
+    return (grid, values, durations, np.nonzero(status == 0)[0], np.nonzero(status == 1)[0],
+            np.nonzero(status == 2)[0])
+
+
+def gen_chooser_next(mods, tmp):
+    """Whole-plugin golden runs: the reference's own GPEIOptChooser.next and
+    GPEIperSecChooser.next on Branin (seeded numpy RNG, serial refinement)."""
+    grid, values, durations, cand, pend, comp = _branin_inputs(mods, 12, 400)
+    out = {}
+    for seed in range(500, 540):
+        ch = mods["GPEIOptChooser"].GPEIOptChooser(tempfile.mkdtemp(prefix="spx_golden_opt_"),
+                                                   mcmc_iters=4, burnin=6, grid_subset=5,
+                                                   use_multiprocessing=0)
+        npr.seed(seed)
+        try:
+            job = ch.next(grid, values, durations, cand, pend, comp)
+        except Exception as e:
+            print("opt seed", seed, "reference raised:", e)
+            continue
+        out.update(opt_seed=seed, opt_is_new=int(isinstance(job, tuple)),
+                   opt_index=int(job[0] if isinstance(job, tuple) else job),
+                   opt_point=np.asarray(job[1] if isinstance(job, tuple) else grid[job]),
+                   opt_hypers=np.array([np.concatenate(([h[0], h[1], h[2]], h[3])) for h in ch.hyper_samples]))
+        break
+    for seed in range(600, 640):
+        ch = mods["GPEIperSecChooser"].GPEIperSecChooser(tempfile.mkdtemp(prefix="spx_golden_ps_"),
+                                                         mcmc_iters=3, burnin=4, grid_subset=4)
+        npr.seed(seed)
+        try:
+            job = ch.next(grid, values, durations, cand, pend, comp)
+        except Exception as e:
+            print("persec seed", seed, "reference raised:", e)
+            continue
+        out.update(ps_seed=seed, ps_is_new=int(isinstance(job, tuple)),
+                   ps_index=int(job[0] if isinstance(job, tuple) else job),
+                   ps_point=np.asarray(job[1] if isinstance(job, tuple) else grid[job]),
+                   ps_hypers=np.array([np.concatenate(([h[0], h[1], h[2]], h[3])) for h in ch.hyper_samples]),
+                   ps_time_hypers=np.array([np.concatenate(([h[0], h[1], h[2]], h[3]))
+                                            for h in ch.time_hyper_samples]))
+        break
+    np.savez_compressed(os.path.join(OUT, "chooser_next.npz"), grid=grid, values=values,
+                        durations=durations, candidates=cand, pending=pend, complete=comp, **out)
+
+
 def gen_slice(mods, tmp):
     util = mods["util"]
     comp, cand, vals, hypers = synthetic_problem(30, 10, 3, 1, 41)
@@ -206,7 +262,7 @@ def gen_slice(mods, tmp):
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_slice):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_slice):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 

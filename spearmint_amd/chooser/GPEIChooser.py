@@ -1,0 +1,55 @@
+"""GP expected-improvement chooser on the candidate grid, MCMC over hypers --
+the MI355X drop-in for spearmint/spearmint/chooser/GPEIChooser.py.
+
+Same plugin API (init / next), same state pickle, same sampler; the EI grid is
+evaluated by libspx.so on the GPU (see _base.py)."""
+from __future__ import absolute_import, print_function
+
+import numpy as np
+
+from .. import util
+from ..helpers import log
+from ._base import GPEIBase
+
+
+def init(expt_dir, arg_string):
+    args = util.unpack_args(arg_string)
+    return GPEIChooser(expt_dir, **args)
+
+
+class GPEIChooser(GPEIBase):
+    # GPEIChooser.py:312 puts the log-normal prior on amp2 itself and its
+    # noiseless sampler has no bounds check on the mean (:323-340).
+    amp2_prior_on_sqrt = False
+    noiseless_checks_mean = False
+    max_ls = 2
+
+    def __del__(self):
+        # the reference persists its hypers when the object dies (:66-83)
+        try:
+            self.save_state()
+        except Exception:
+            pass
+
+    def next(self, grid, values, durations, candidates, pending, complete):
+        # Too little data for a GP: take the first candidate (:127-128). No GPU touched.
+        if complete.shape[0] < 2:
+            return int(candidates[0])
+        if self.D == -1:
+            self._real_init(np.asarray(grid).shape[1], np.asarray(values)[complete])
+        comp, cand, pend, vals = self._split(grid, values, candidates, pending, complete)
+
+        if self.mcmc_iters <= 0:
+            raise NotImplementedError("mcmc_iters=0 (ML-II hyper optimisation, gp.py:181-292) is outside "
+                                      "the GPU hot path; use mcmc_iters >= 1")
+        # The reference alternates "sample hypers" and "compute_ei" (:145-151).
+        # Without pending experiments compute_ei consumes no random numbers, so
+        # drawing all H samples first and scoring them in one GPU call is the
+        # same computation.
+        rows = []
+        for _ in range(self.mcmc_iters):
+            self.sample_hypers(comp, vals)
+            self._log_hypers()
+            rows.append(self.current_hyper_row())
+        best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand, vals, np.array(rows))
+        return int(candidates[best])

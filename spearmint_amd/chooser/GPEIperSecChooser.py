@@ -1,0 +1,176 @@
+"""Expected improvement per second: a second GP on log-durations, EI divided by
+the predicted duration -- the MI355X drop-in for
+spearmint/spearmint/chooser/GPEIperSecChooser.py.
+
+Reference defects on this path and what this module does about them
+(SURVEY.md section 8(a) row A10):
+  (i)  ei_over_hypers returns from inside its loop (:302), so only draw 0 is
+       ever evaluated;
+  (ii) time_hyper_samples is never cleared (:199 clears only hyper_samples), so
+       ei_over_hypers pairs draw i with a burn-in time sample.
+The default here is the intended semantics (all draws, paired samples);
+``ref_compat=1`` reproduces (i) and (ii) for side-by-side comparisons."""
+from __future__ import absolute_import, print_function
+
+import os
+
+import numpy as np
+import scipy.optimize as spo
+
+from .. import hostgp
+from .. import util
+from ..helpers import log
+from ._base import GPEIBase, _as_bool
+
+
+def init(expt_dir, arg_string):
+    args = util.unpack_args(arg_string)
+    return GPEIperSecChooser(expt_dir, **args)
+
+
+class GPEIperSecChooser(GPEIBase):
+    amp2_prior_on_sqrt = False      # objective GP: log(amp2) (:626, :672)
+    noiseless_checks_mean = True    # :660-661
+    max_ls = 10                     # :74
+    time_noise_scale = 0.1
+    time_amp2_scale = 1
+    time_max_ls = 10
+
+    def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
+                 noiseless=False, burnin=100, grid_subset=20, ref_compat=False, **kw):
+        GPEIBase.__init__(self, expt_dir, covar=covar, mcmc_iters=mcmc_iters,
+                          pending_samples=pending_samples, noiseless=noiseless, **kw)
+        self.stats_file = os.path.join(expt_dir, self.__module__ + "_hyperparameters.txt")
+        self.burnin = int(burnin)
+        self.needs_burnin = True
+        self.grid_subset = int(grid_subset)
+        self.ref_compat = _as_bool(ref_compat)
+        self.hyper_samples = []
+        self.time_hyper_samples = []
+
+    # -- state (:83-143) -----------------------------------------------------------
+    def _state_dict(self):
+        d = GPEIBase._state_dict(self)
+        d.update({"time_ls": self.time_ls, "time_amp2": self.time_amp2,
+                  "time_noise": self.time_noise, "time_mean": self.time_mean})
+        return d
+
+    def _apply_state(self, state):
+        GPEIBase._apply_state(self, state)
+        self.time_ls = state["time_ls"]
+        self.time_amp2 = state["time_amp2"]
+        self.time_noise = state["time_noise"]
+        self.time_mean = state["time_mean"]
+
+    def _fresh_state(self, dims, values, durations):
+        GPEIBase._fresh_state(self, dims, values)
+        self.time_ls = np.ones(self.D)
+        self.time_amp2 = np.std(durations) + 1e-4
+        self.time_noise = 1e-3
+        self.time_mean = np.mean(np.log(durations))
+
+    def dump_hypers(self):
+        self.save_state()
+
+    # -- sampling (:550-563) ---------------------------------------------------------
+    def sample_hypers(self, comp, vals, durs):
+        GPEIBase.sample_hypers(self, comp, vals)
+        self.time_mean, self.time_amp2, self.time_noise = self._draw_mean_amp_noise(
+            comp, durs, self.time_ls, [self.time_mean, self.time_amp2, self.time_noise],
+            self.time_noise_scale, self.time_amp2_scale, False, on_sqrt=True)
+        self.time_ls = self._draw_ls(comp, durs, self.time_mean, self.time_amp2, self.time_noise,
+                                     self.time_ls, self.time_max_ls)
+        self.hyper_samples.append((self.mean, self.noise, self.amp2, self.ls))
+        self.time_hyper_samples.append((self.time_mean, self.time_noise, self.time_amp2, self.time_ls))
+
+    @staticmethod
+    def _rows(samples):
+        return np.array([np.concatenate(([h[0], h[1], h[2]], np.asarray(h[3], dtype=float)))
+                         for h in samples])
+
+    def _paired_samples(self):
+        """(objective rows, time rows) that ei_over_hypers evaluates."""
+        H = self.mcmc_iters
+        if self.ref_compat:
+            # (i) only draw 0, (ii) paired with time_hyper_samples[0] of the never-cleared list
+            return self._rows(self.hyper_samples[:1]), self._rows(self.time_hyper_samples[:1])
+        return self._rows(self.hyper_samples[:H]), self._rows(self.time_hyper_samples[-H:])
+
+    # -- the hot path ----------------------------------------------------------------
+    def ei_per_s_over_hypers_gpu(self, comp, pend, cand, vals, durs):
+        if pend.shape[0] > 0:
+            raise NotImplementedError("pending-experiment fantasies (GPEIperSecChooser.py:492-548) "
+                                      "are not on the GPU path yet")
+        rows, trows = self._paired_samples()
+        idx, val, mean, draws = self.engine().ei_per_sec_grid(comp, vals, durs, cand, rows, trows,
+                                                              want_mean=True, want_draws=False)
+        if self.ref_compat:
+            # the other mcmc_iters-1 columns of overall_ei stay zero in the reference
+            mean = mean / float(self.mcmc_iters)
+        return idx, mean
+
+    def _refine(self, points, comp, vals, durs):
+        rows, trows = (self.hyper_samples[:self.mcmc_iters],
+                       (self.time_hyper_samples[:self.mcmc_iters] if self.ref_compat
+                        else self.time_hyper_samples[-self.mcmc_iters:]))
+        models = [hostgp.PerSecPointModel(comp, vals, durs, h, t) for h, t in zip(rows, trows)]
+
+        def objective(x):
+            total, grad = 0.0, np.zeros(x.shape[0])
+            for m in models:
+                e, g = m.neg_ei_and_grad(x)
+                total += e
+                grad = grad + g
+            return total, grad
+
+        bounds = [(0, 1)] * comp.shape[1]
+        out = np.array(points, dtype=float, copy=True)
+        for i in range(out.shape[0]):
+            log("Optimizing candidate %d/%d" % (i + 1, out.shape[0]))
+            out[i, :] = spo.fmin_l_bfgs_b(objective, out[i, :].flatten(), bounds=bounds, disp=0)[0]
+        return out
+
+    # -- plugin entry (:155-281) -------------------------------------------------------
+    def next(self, grid, values, durations, candidates, pending, complete):
+        if complete.shape[0] < 2:
+            return int(candidates[0])
+        durations = np.asarray(durations, dtype=np.float64)
+        if self.D == -1:
+            self._real_init(np.asarray(grid).shape[1], np.asarray(values)[complete],
+                            durations[complete])
+        comp, cand, pend, vals = self._split(grid, values, candidates, pending, complete)
+        durs = np.log(durations[complete]).squeeze()   # log domain keeps times positive (:174-176)
+        numcand = cand.shape[0]
+        best_comp = np.argmin(vals)
+        cand2 = np.vstack((np.random.randn(10, comp.shape[1]) * 0.001 + comp[best_comp, :], cand))
+
+        if self.mcmc_iters <= 0:
+            raise NotImplementedError("mcmc_iters=0 is outside the GPU hot path")
+
+        if self.needs_burnin:
+            for it in range(self.burnin):
+                self.sample_hypers(comp, vals, durs)
+                self._log_hypers("BURN %d/%d] " % (it + 1, self.burnin))
+            self.needs_burnin = False
+
+        self.hyper_samples = []
+        if not self.ref_compat:
+            self.time_hyper_samples = []
+        for it in range(self.mcmc_iters):
+            self.sample_hypers(comp, vals, durs)
+            self._log_hypers("%d/%d] " % (it + 1, self.mcmc_iters))
+            log("%d/%d] time_mean: %.2fs time_amp: %.2f  time_noise: %.4f time_min_ls: %.4f  time_max_ls: %.4f"
+                % (it + 1, self.mcmc_iters, np.exp(self.time_mean), np.sqrt(self.time_amp2),
+                   np.exp(self.time_noise), np.min(self.time_ls), np.max(self.time_ls)))
+        self.dump_hypers()
+
+        _, mean1 = self.ei_per_s_over_hypers_gpu(comp, pend, cand2, vals, durs)
+        keep = np.argsort(mean1)[-self.grid_subset:]
+        refined = self._refine(cand2[keep, :], comp, vals, durs)
+
+        cand_all = np.vstack((cand, refined))
+        best, _ = self.ei_per_s_over_hypers_gpu(comp, pend, cand_all, vals, durs)
+        self.dump_hypers()
+        if best >= numcand:
+            return (int(numcand), cand_all[best, :])
+        return int(candidates[best])

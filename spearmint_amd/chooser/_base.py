@@ -1,0 +1,195 @@
+"""Shared machinery of the MI355X GP-EI choosers.
+
+The three public modules (GPEIChooser, GPEIOptChooser, GPEIperSecChooser) keep
+the reference's plugin contract --
+
+    module.init(expt_dir, arg_string) -> chooser
+    chooser.next(grid, values, durations, candidates, pending, complete)
+        -> int grid index | (int, ndarray) new off-grid point
+
+(spearmint/spearmint/main.py:164-165, :254; spearmint-lite.py:99-100, :187-190)
+-- and differ from the reference only in WHERE the EI grid is computed: the
+``for mcmc_iter: compute_ei(...)`` / ``ei_over_hypers`` block plus the
+``argmax(mean(...))`` is one call into libspx.so (HIP, gfx950) through
+``spearmint_amd.engine``.  Hyper-parameter slice sampling, state pickles,
+logging and the 20-point L-BFGS refinement stay on the host, as SURVEY.md
+section 8(b) lays out.  There is no numpy fallback for the EI grid: if the
+library or the GPU is missing, ``next`` raises.
+
+Python 2/3 common subset on purpose (the reference driver is Python 2).
+"""
+from __future__ import absolute_import, print_function
+
+import os
+
+import numpy as np
+import numpy.random as npr
+
+from .. import hostgp
+from .. import util
+from ..helpers import log, pickle_atomically, unpickle
+from ..Locker import Locker
+
+
+def _as_bool(v):
+    return bool(int(v))
+
+
+class GPEIBase(object):
+    """State + sampler + GPU dispatch common to the GP-EI choosers."""
+
+    # knobs the subclasses override
+    max_ls = 2                     # top-hat prior on length scales
+    noise_scale = 0.1              # horseshoe prior scale
+    amp2_scale = 1                 # log-normal prior scale
+    amp2_prior_on_sqrt = False     # lognormal on sqrt(amp2) (Opt) vs amp2 (GPEIChooser)
+    noiseless_checks_mean = True   # mean in [min, max] also in noiseless mode
+    state_keys = ("dims", "ls", "amp2", "noise", "mean")
+
+    def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
+                 noiseless=False, device=0, lib=None, **unused):
+        if covar != "Matern52":
+            # the HIP path implements the ARD Matern-5/2 kernel named by the north star
+            raise ValueError("spearmint_amd choosers support covar=Matern52 only (got %r)" % (covar,))
+        self.expt_dir = expt_dir
+        self.locker = Locker()
+        self.state_pkl = os.path.join(expt_dir, self.__module__ + ".pkl")
+        self.mcmc_iters = int(mcmc_iters)
+        self.pending_samples = int(pending_samples)
+        self.noiseless = _as_bool(noiseless)
+        self.device = int(device)
+        self.lib_path = lib
+        self.D = -1
+        self._eng = None          # created lazily in next(): never before a fork, never pickled
+        self.last_overall_ei = None
+
+    # -- GPU handle -----------------------------------------------------------
+    def engine(self):
+        if self._eng is None:
+            from ..engine import Engine
+            self._eng = Engine(self.device, self.lib_path)
+        return self._eng
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_eng"] = None          # ctypes handles / HIP contexts do not survive pickling or fork
+        return d
+
+    # -- persistent state -------------------------------------------------------
+    def _state_dict(self):
+        return {"dims": self.D, "ls": self.ls, "amp2": self.amp2, "noise": self.noise,
+                "mean": self.mean}
+
+    def _apply_state(self, state):
+        self.D = state["dims"]
+        self.ls = state["ls"]
+        self.amp2 = state["amp2"]
+        self.noise = state["noise"]
+        self.mean = state["mean"]
+
+    def _fresh_state(self, dims, values):
+        """Defaults of GPEIChooser.py:100-113."""
+        self.D = dims
+        self.ls = np.ones(self.D)
+        self.amp2 = np.std(values) + 1e-4
+        self.noise = 1e-3
+        self.mean = np.mean(values)
+
+    def save_state(self):
+        if self.D == -1:
+            return
+        self.locker.lock_wait(self.state_pkl)
+        try:
+            pickle_atomically(self._state_dict(), self.state_pkl)
+        finally:
+            self.locker.unlock(self.state_pkl)
+
+    def _real_init(self, dims, values, *more):
+        self.locker.lock_wait(self.state_pkl)
+        try:
+            if os.path.exists(self.state_pkl):
+                self._apply_state(unpickle(self.state_pkl))
+                self._loaded_from_disk = True
+            else:
+                self._fresh_state(dims, values, *more)
+                self._loaded_from_disk = False
+        finally:
+            self.locker.unlock(self.state_pkl)
+
+    # -- hyper-parameter sampling (host; GPEIChooser.py:268-346) -----------------
+    def _amp2_logprior(self, amp2, scale):
+        a = np.sqrt(amp2) if self.amp2_prior_on_sqrt else amp2
+        return -0.5 * (np.log(a) / scale) ** 2
+
+    def _draw_mean_amp_noise(self, comp, vals, ls, cur, noise_scale, amp2_scale,
+                             noiseless, on_sqrt=None):
+        """One joint slice move over [mean, amp2, noise]; returns the new triple."""
+        lo, hi = np.min(vals), np.max(vals)
+        check_mean = (not noiseless) or self.noiseless_checks_mean
+        sqrt_prior = self.amp2_prior_on_sqrt if on_sqrt is None else on_sqrt
+
+        def logprob(h):
+            mean, amp2 = h[0], h[1]
+            noise = 1e-3 if noiseless else h[2]
+            if check_mean and (mean > hi or mean < lo):
+                return -np.inf
+            if amp2 < 0 or noise < 0:
+                return -np.inf
+            lp = hostgp.data_logprob(comp, vals, mean, amp2, noise, ls)
+            if not noiseless:
+                lp += np.log(np.log(1 + (noise_scale / noise) ** 2))
+            a = np.sqrt(amp2) if sqrt_prior else amp2
+            lp -= 0.5 * (np.log(a) / amp2_scale) ** 2
+            return lp
+
+        new = util.slice_sample(np.array(cur, dtype=float), logprob, compwise=False)
+        return new[0], new[1], (1e-3 if noiseless else new[2])
+
+    def _draw_ls(self, comp, vals, mean, amp2, noise, ls, max_ls):
+        def logprob(cand_ls):
+            if np.any(cand_ls < 0) or np.any(cand_ls > max_ls):
+                return -np.inf
+            return hostgp.data_logprob(comp, vals, mean, amp2, noise, cand_ls)
+        return util.slice_sample(ls, logprob, compwise=True)
+
+    def sample_hypers(self, comp, vals):
+        if self.noiseless:
+            self.noise = 1e-3
+        self.mean, self.amp2, self.noise = self._draw_mean_amp_noise(
+            comp, vals, self.ls, [self.mean, self.amp2, self.noise],
+            self.noise_scale, self.amp2_scale, self.noiseless)
+        self.ls = self._draw_ls(comp, vals, self.mean, self.amp2, self.noise, self.ls, self.max_ls)
+
+    def current_hyper_row(self):
+        return np.concatenate(([self.mean, self.noise, self.amp2], np.asarray(self.ls, dtype=float)))
+
+    def _log_hypers(self, prefix=""):
+        log("%smean: %f  amp: %f  noise: %f  min_ls: %f  max_ls: %f"
+            % (prefix, self.mean, np.sqrt(self.amp2), self.noise, np.min(self.ls), np.max(self.ls)))
+
+    # -- the hot path: one call into libspx ---------------------------------------
+    def ei_over_hypers_gpu(self, comp, pend, cand, vals, hyper_rows, want_draws=True):
+        """overall_ei[M, H] and the index of argmax(mean) -- the replacement of
+        the reference's compute_ei loop (GPEIChooser.py:143-153,
+        GPEIOptChooser.py:331-341).  Raises numpy.linalg.LinAlgError when a
+        covariance is not positive definite, exactly where spla.cholesky would."""
+        if pend.shape[0] > 0:
+            raise NotImplementedError(
+                "pending-experiment fantasies (GPEIChooser.py:209-266) are not on the GPU path yet; "
+                "run with --max-concurrent=1 / no 'P' lines")
+        hyper_rows = np.ascontiguousarray(np.atleast_2d(hyper_rows), dtype=np.float64)
+        idx, val, mean, draws = self.engine().ei_grid(comp, vals, cand, hyper_rows,
+                                                      want_mean=True, want_draws=want_draws)
+        self.last_overall_ei = draws
+        self.last_ei_mean = mean
+        return idx, mean, draws
+
+    @staticmethod
+    def _split(grid, values, candidates, pending, complete):
+        grid = np.asarray(grid, dtype=np.float64)
+        values = np.asarray(values, dtype=np.float64)
+        comp = grid[complete, :]
+        cand = grid[candidates, :]
+        pend = grid[pending, :]
+        vals = values[complete]
+        return comp, cand, pend, vals

@@ -61,7 +61,8 @@ __device__ __forceinline__ double matern52_corr(double g, double s1, double s2)
 {
 #pragma clang fp contract(off)
     const double t = (g - s1) - s2;
-    double r2 = fmax(-t, 0.0);
+    const double nt = -t;
+    double r2 = (nt < 0.0) ? 0.0 : nt;  // np.maximum(., 0): NaN propagates (fmax would drop it)
     r2 = fabs(r2);
     const double r = sqrt(r2);
     const double poly = (1.0 + SQRT5 * r) + (5.0 / 3.0) * r2;

@@ -1,0 +1,134 @@
+"""Host-side (numpy) GP pieces that stay on the CPU by design.
+
+What lives here is everything the choosers do *outside* the EI-grid hot path
+(SURVEY.md section 8(a) marks it out of scope / "next"):
+
+  * the log-posterior evaluated thousands of times by the sequential slice
+    sampler (spearmint/spearmint/chooser/GPEIChooser.py:276-346), and
+  * the EI value + gradient used by the L-BFGS-B refinement of the 20 best
+    candidates (GPEIOptChooser.py:360-440), a 20-point problem.
+
+The EI grid itself (candidates x hyper draws) never comes through this module:
+it goes to libspx.so via spearmint_amd.engine, and there is no code path that
+substitutes these functions for it.
+"""
+from __future__ import absolute_import, print_function
+
+import numpy as np
+import scipy.linalg as spla
+import scipy.stats as sps
+
+ROOT5 = np.sqrt(5.0)
+
+
+def scaled_sqdist(ls, a, b=None):
+    """Pairwise squared distance of a/ls and b/ls in the expanded (GEMM) form,
+    clamped at zero (gp.py:34-54)."""
+    sa = a / ls
+    sb = sa if b is None else b / ls
+    cross = np.dot(sa, 2 * sb.T)
+    na = np.sum(sa * sa, axis=1)[:, None]
+    nb = np.sum(sb * sb, axis=1)[None, :]
+    return np.maximum(-(cross - na - nb), 0.0)
+
+
+def matern52(ls, a, b=None):
+    """gp.py:120-127."""
+    r2 = np.abs(scaled_sqdist(ls, a, b))
+    r = np.sqrt(r2)
+    return (1.0 + ROOT5 * r + (5.0 / 3.0) * r2) * np.exp(-ROOT5 * r)
+
+
+def matern52_grad_wrt_first(ls, a, b):
+    """d k(a_i, b_j) / d a_i, shape (Na, Nb, D): dk/dr2 * dr2/da
+    (gp.py:129-132 with gp.py:56-85)."""
+    sa = a / ls
+    sb = b / ls
+    r = np.sqrt(scaled_sqdist(ls, a, b))
+    dk_dr2 = -(5.0 / 6.0) * np.exp(-ROOT5 * r) * (1 + ROOT5 * r)
+    dr2_da = 2.0 * (sa[:, None, :] - sb[None, :, :]) * (1.0 / ls)
+    return dk_dr2[:, :, None] * dr2_da
+
+
+def obs_cov(amp2, noise, ls, x):
+    """amp2 (k + 1e-6 I) + noise I  (GPEIChooser.py:117-122, :190)."""
+    n = x.shape[0]
+    return amp2 * (matern52(ls, x) + 1e-6 * np.eye(n)) + noise * np.eye(n)
+
+
+def data_logprob(x, y, mean, amp2, noise, ls):
+    """-sum log diag L - 0.5 r^T K^-1 r  (GPEIChooser.py:281-285).
+    Lets numpy.linalg.LinAlgError propagate, as the reference does."""
+    chol = spla.cholesky(obs_cov(amp2, noise, ls, x), lower=True)
+    resid = y - mean
+    sol = spla.cho_solve((chol, True), resid)
+    return -np.sum(np.log(np.diag(chol))) - 0.5 * np.dot(resid, sol)
+
+
+class PointModel(object):
+    """Posterior at ONE hyper draw, factorised once, for evaluating EI and its
+    gradient at a handful of points during local refinement."""
+
+    def __init__(self, comp, vals, hyper):
+        self.mean, self.noise, self.amp2 = float(hyper[0]), float(hyper[1]), float(hyper[2])
+        self.ls = np.asarray(hyper[3], dtype=float)
+        self.comp = comp
+        self.best = np.min(vals)
+        self.chol = spla.cholesky(obs_cov(self.amp2, self.noise, self.ls, comp), lower=True)
+        self.alpha = spla.cho_solve((self.chol, True), vals - self.mean)
+
+    def neg_ei_and_grad(self, x):
+        """(-sum EI, gradient) at the point(s) x, in the reference's scaling:
+        GPEIOptChooser.py:391-440 returns 0.5 x the analytic gradient (its
+        grad_xp carries an extra factor one half); L-BFGS-B sees exactly that."""
+        x = np.reshape(x, (-1, self.comp.shape[1]))
+        kx = self.amp2 * matern52(self.ls, self.comp, x)
+        beta = spla.solve_triangular(self.chol, kx, lower=True)
+        m = np.dot(kx.T, self.alpha) + self.mean
+        v = self.amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
+        s = np.sqrt(v)
+        u = (self.best - m) / s
+        cdf = sps.norm.cdf(u)
+        pdf = sps.norm.pdf(u)
+        ei = s * (u * cdf + pdf)
+        dk = np.squeeze(matern52_grad_wrt_first(self.ls, self.comp, x))
+        d_m = np.dot(self.alpha.T, dk)
+        d_v = np.dot(-2 * spla.cho_solve((self.chol, True), kx).T, dk)
+        grad = 0.5 * self.amp2 * (d_m * (-cdf) + d_v * (0.5 * pdf / s))
+        return -np.sum(ei), grad.flatten()
+
+
+class PerSecPointModel(PointModel):
+    """PointModel plus the log-duration GP (mean only) for EI-per-second
+    refinement (GPEIperSecChooser.py:349-434)."""
+
+    def __init__(self, comp, vals, log_durs, hyper, time_hyper):
+        PointModel.__init__(self, comp, vals, hyper)
+        self.t_mean, self.t_noise, self.t_amp2 = (float(time_hyper[0]), float(time_hyper[1]),
+                                                  float(time_hyper[2]))
+        self.t_ls = np.asarray(time_hyper[3], dtype=float)
+        t_chol = spla.cholesky(obs_cov(self.t_amp2, self.t_noise, self.t_ls, comp), lower=True)
+        self.t_alpha = spla.cho_solve((t_chol, True), log_durs - self.t_mean)
+
+    def neg_ei_and_grad(self, x):
+        x = np.reshape(x, (-1, self.comp.shape[1]))
+        kt = self.t_amp2 * matern52(self.t_ls, self.comp, x)
+        time_m = np.exp(np.dot(kt.T, self.t_alpha) + self.t_mean)
+        dkt = np.squeeze(matern52_grad_wrt_first(self.t_ls, self.comp, x))
+
+        kx = self.amp2 * matern52(self.ls, self.comp, x)
+        beta = spla.solve_triangular(self.chol, kx, lower=True)
+        m = np.dot(kx.T, self.alpha) + self.mean
+        v = self.amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
+        s = np.sqrt(v)
+        u = (self.best - m) / s
+        cdf = sps.norm.cdf(u)
+        pdf = sps.norm.pdf(u)
+        ei = s * (u * cdf + pdf)
+        dk = np.squeeze(matern52_grad_wrt_first(self.ls, self.comp, x))
+        d_m = np.dot(self.alpha.T, dk)
+        d_v = np.dot(-2 * spla.cho_solve((self.chol, True), kx).T, dk)
+        g = 0.5 * self.amp2 * (d_m * (-cdf) + d_v * (0.5 * pdf / s))
+        g_t = 0.5 * self.t_amp2 * np.dot(self.t_alpha.T, dkt) * time_m
+        g = (time_m * g - ei * g_t) / (time_m ** 2)
+        return -np.sum(ei / time_m), g.flatten()

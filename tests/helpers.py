@@ -1,0 +1,56 @@
+"""Test-only helpers: an oracle-backed stand-in for the GPU engine so the host
+logic of the choosers can be exercised on a CPU-only box.  It lives under
+tests/ and is injected explicitly (chooser._eng = OracleEngine()); the product
+package has no such fallback."""
+import numpy as np
+
+from oracle import gp_ei_oracle as orc
+
+
+class OracleEngine(object):
+    def __init__(self):
+        self.calls = []
+
+    def ei_grid(self, comp, vals, cand, hypers, want_mean=True, want_draws=False, flags=0):
+        ei = orc.ei_over_hypers(comp, cand, vals, hypers)
+        mean = np.mean(ei, axis=1)
+        idx = int(np.argmax(mean))
+        self.calls.append(("ei_grid", cand.shape[0], np.atleast_2d(hypers).shape[0]))
+        return idx, float(mean[idx]), mean, (ei if want_draws else None)
+
+    def ei_per_sec_grid(self, comp, vals, log_durs, cand, hypers, time_hypers,
+                        want_mean=True, want_draws=False, flags=0):
+        ei = orc.ei_per_s_over_hypers(comp, cand, vals, log_durs, hypers, time_hypers)
+        mean = np.mean(ei, axis=1)
+        idx = int(np.argmax(mean))
+        self.calls.append(("ei_per_sec_grid", cand.shape[0], np.atleast_2d(hypers).shape[0]))
+        return idx, float(mean[idx]), mean, (ei if want_draws else None)
+
+
+def np_mean_device_order(row):
+    """Python mirror of k_mean_over_draws (predict_kernels.hip): numpy's
+    pairwise summation order, then / H."""
+    def pw(a):
+        n = len(a)
+        if n < 8:
+            res = -0.0
+            for x in a:
+                res = res + x
+            return res
+        if n <= 128:
+            r = [a[q] for q in range(8)]
+            i = 8
+            while i < n - (n % 8):
+                for q in range(8):
+                    r[q] = r[q] + a[i + q]
+                i += 8
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            while i < n:
+                res = res + a[i]
+                i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pw(a[:n2]) + pw(a[n2:])
+    row = [np.float64(x) for x in row]
+    return (np.float64(0.0) + pw(row)) / np.float64(len(row))

@@ -1,0 +1,82 @@
+"""Candidate sharding + the single all-reduce, on CPU with gloo (world_size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from spearmint_amd import dist as sd
+
+
+def test_shard_bounds_cover_and_balance():
+    for M, P in [(10, 3), (1000000, 8), (7, 8), (128, 2)]:
+        spans = [sd.shard_bounds(M, P, r) for r in range(P)]
+        assert spans[0][0] == 0 and spans[-1][1] == M
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(P - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_pick_best_numpy_rule():
+    nan = float("nan")
+    assert sd.pick_best([[1.0, 5], [3.0, 9], [3.0, 7]])[0] == 7        # tie -> lowest index
+    assert sd.pick_best([[1.0, 5], [nan, 9], [3.0, 7]])[0] == 9        # NaN beats everything
+    assert sd.pick_best([[nan, 12], [nan, 9]])[0] == 9                 # first NaN
+    assert sd.pick_best([[0.0, -1], [2.0, 4]])[0] == 4                 # empty shard ignored
+    # same answer as numpy on the concatenated vector
+    rs = np.random.RandomState(0)
+    for _ in range(50):
+        v = rs.rand(40); v[rs.randint(40, size=3)] = v[0]
+        if rs.rand() < 0.3:
+            v[rs.randint(40)] = nan
+        recs = []
+        for r in range(4):
+            lo, hi = sd.shard_bounds(40, 4, r)
+            j = int(np.argmax(v[lo:hi]))
+            recs.append([v[lo + j], lo + j])
+        assert sd.pick_best(recs)[0] == int(np.argmax(v))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as tdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    # a fixed global EI vector; each rank scores its shard and the all-reduce picks the winner
+    v = np.random.RandomState(123).rand(1001)
+    v[700] = v[100] = 2.0                      # tie across shards -> index 100 must win
+    lo, hi = sd.shard_bounds(v.shape[0], world, rank)
+    j = int(np.argmax(v[lo:hi]))
+    out1 = sd.allreduce_best(v[lo + j], lo + j)
+    v2 = v.copy(); v2[900] = np.nan             # NaN in the last shard wins
+    j2 = int(np.argmax(v2[lo:hi]))
+    out2 = sd.allreduce_best(v2[lo + j2], lo + j2)
+    q.put((rank, out1, out2))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_allreduce_best_gloo_world2():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, o1, o2 in res:
+        assert o1[0] == 100 and o1[1] == 2.0
+        assert o2[0] == 900 and np.isnan(o2[1])
+
+
+def test_allreduce_without_group_is_identity():
+    assert sd.allreduce_best(1.5, 42) == (42, 1.5)

@@ -1,0 +1,303 @@
+"""Parity of the HIP path (through the C ABI, libspx.so) with the CPU oracle and
+with the golden vectors produced by running the reference.  Needs an MI355X.
+
+Tolerances (BASELINE.json north_star): identical argmax index for fixed
+hyper-parameters; EI within 1e-5 relative (we assert 1e-7: measured ~1e-9)
+for every candidate with EI >= 1e-280, NaN positions identical.
+"""
+import os
+
+import numpy as np
+import numpy.random as npr
+import pytest
+
+from oracle import gp_ei_oracle as orc
+from spearmint_amd import dist as sd
+from spearmint_amd.synthetic import synthetic_problem
+
+pytestmark = pytest.mark.gpu
+
+EI_RTOL = 1e-7
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from spearmint_amd.engine import Engine
+    e = Engine(0)   # raises if libspx.so or the GPU is missing -- no fallback
+    yield e
+    e.close()
+
+
+def assert_ei_close(got, ref, rtol=EI_RTOL):
+    got = np.asarray(got); ref = np.asarray(ref)
+    assert got.shape == ref.shape
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    big = np.isfinite(ref) & (ref >= 1e-280)
+    if big.any():
+        assert np.max(np.abs(got[big] - ref[big]) / ref[big]) <= rtol
+    small = np.isfinite(ref) & (ref < 1e-280)
+    assert np.all(got[small] <= 1e-270)
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ---- golden vectors (outputs of the reference itself) -------------------------
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_golden_ei(eng, golden_dir, case):
+    g = _g(golden_dir, "ei_small_%s.npz" % case)
+    idx, val, mean, draws = eng.ei_grid(g["comp"], g["vals"], g["cand"], g["hypers"], want_draws=True)
+    assert_ei_close(draws, g["ei"])
+    assert idx == int(g["best"])
+    assert np.array_equal(mean, np.mean(draws, axis=1))      # numpy summation order on the device
+    assert val == mean[idx]
+
+
+def test_golden_stage_arrays(eng, golden_dir):
+    g = _g(golden_dir, "ei_small_a.npz")
+    eng.set_observations(g["comp"], g["vals"]); eng.set_candidates(g["cand"]); eng.set_hypers(g["hypers"])
+    eng.factor()
+    for h in range(g["hypers"].shape[0]):
+        K, L, alpha = eng.get_factor(h)
+        assert np.allclose(K, g["K"][h], rtol=1e-13, atol=1e-15)
+        assert np.allclose(L @ L.T, g["K"][h], rtol=1e-12, atol=1e-14)
+        assert np.allclose(eng.get_cross_cov(h), g["Kstar"][h], rtol=1e-12, atol=1e-15)
+
+
+def test_golden_branin_c1(eng, golden_dir):
+    g = _g(golden_dir, "branin_c1.npz")
+    grid, values = g["grid"], g["values"]
+    comp, cand, vals = grid[g["complete"]], grid[g["candidates"]], values[g["complete"]]
+    idx, _, _, draws = eng.ei_grid(comp, vals, cand, g["hypers"], want_draws=True)
+    assert_ei_close(draws, g["ei"])
+    assert int(g["candidates"][idx]) == int(g["job"])
+
+
+def test_golden_persec(eng, golden_dir):
+    g = _g(golden_dir, "ei_persec.npz")
+    idx, _, mean, draws = eng.ei_per_sec_grid(g["comp"], g["vals"], g["log_durs"], g["cand"],
+                                              g["hypers"], g["time_hypers"], want_draws=True)
+    assert_ei_close(draws, g["ei"])
+    assert idx == int(np.argmax(np.mean(g["ei"], axis=1)))
+    # the reference's literal (early-return) behaviour = draw 0 only
+    idx0, _, _, d0 = eng.ei_per_sec_grid(g["comp"], g["vals"], g["log_durs"], g["cand"],
+                                         g["hypers"][:1], g["time_hypers"][:1], want_draws=True)
+    assert_ei_close(d0[:, 0], g["literal"][:, 0])
+    assert idx0 == int(np.argmax(np.mean(g["literal"], axis=1)))
+
+
+# ---- oracle on seeded inputs, per stage ----------------------------------------
+@pytest.mark.parametrize("N,M,D,H,seed", [
+    (2, 5, 1, 1, 1), (3, 127, 2, 2, 2), (127, 128, 3, 3, 3), (128, 129, 4, 7, 4), (129, 1000, 5, 8, 5),
+    (200, 513, 9, 9, 6), (300, 700, 16, 2, 7), (257, 300, 17, 2, 8), (256, 256, 33, 2, 9),
+    (512, 2000, 64, 2, 10), (700, 900, 100, 1, 11), (1000, 3000, 32, 3, 12),
+])
+def test_oracle_stages(eng, N, M, D, H, seed):
+    comp, cand, vals, hypers = synthetic_problem(N, M, D, H, seed, near=min(10, M))
+    eng.set_observations(comp, vals); eng.set_candidates(cand); eng.set_hypers(hypers)
+    eng.factor()
+    from spearmint_amd.engine import FLAG_KEEP_MOMENTS
+    eng.ei_run(FLAG_KEEP_MOMENTS)
+    draws = eng.ei_draws()
+    ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert_ei_close(draws, ref)
+    assert eng.best()[0] == orc.choose(ref)
+    st = {}
+    orc.compute_ei(comp, cand, vals, hypers[0], stages=st)
+    K, L, alpha = eng.get_factor(0)
+    assert np.allclose(K, st["K"], rtol=1e-12, atol=1e-14)
+    assert np.linalg.norm(L @ L.T - st["K"]) / np.linalg.norm(st["K"]) <= 1e-13
+    assert np.allclose(alpha, st["alpha"], rtol=1e-8, atol=1e-10 * np.abs(st["alpha"]).max())
+    m, v = eng.get_moments(0)
+    assert np.allclose(m, st["func_m"], rtol=1e-9, atol=1e-10)
+    assert np.allclose(v, st["func_v"], rtol=1e-7, atol=1e-12)
+
+
+def test_c2_full_size_every_value(eng):
+    """BASELINE config 2 at full size: 256 obs, 20 000 candidates, 8-D, 10 draws."""
+    comp, cand, vals, hypers = synthetic_problem(256, 20000, 8, 10, 2000)
+    idx, val, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert_ei_close(draws, ref)
+    assert idx == orc.choose(ref)
+    assert np.array_equal(mean, np.mean(draws, axis=1))
+
+
+def test_c2_noiseless_hypers(eng):
+    comp, cand, vals, hypers = synthetic_problem(256, 5000, 8, 4, 2001)
+    hypers[:, 1] = 1e-3          # noise pinned as in GPEIChooser.py:270
+    idx, _, _, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert_ei_close(draws, ref)
+    assert idx == orc.choose(ref)
+
+
+# ---- edge cases -------------------------------------------------------------------
+def test_single_candidate_and_minimal_sizes(eng):
+    comp, cand, vals, hypers = synthetic_problem(2, 1, 1, 1, 21, near=0)
+    idx, val, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    assert idx == 0 and draws.shape == (1, 1)
+    assert_ei_close(draws, orc.ei_over_hypers(comp, cand, vals, hypers))
+
+
+def test_ties_go_to_the_first_index(eng):
+    comp, cand, vals, hypers = synthetic_problem(40, 600, 3, 3, 22)
+    cand[:] = cand[17]                       # every candidate identical -> every EI identical
+    idx, _, mean, _ = eng.ei_grid(comp, vals, cand, hypers)
+    assert np.all(mean == mean[0]) and idx == 0
+    cand = np.random.RandomState(1).rand(600, 3)
+    cand[400] = cand[30]                     # a duplicated row
+    idx2, _, mean2, _ = eng.ei_grid(comp, vals, cand, hypers)
+    assert mean2[400] == mean2[30] and idx2 == int(np.argmax(mean2))
+
+
+def test_nan_candidate_wins_like_numpy(eng):
+    comp, cand, vals, hypers = synthetic_problem(30, 500, 2, 2, 23)
+    cand[321, 0] = np.nan
+    cand[400, 1] = np.nan
+    idx, val, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert np.isnan(ref[321]).all() and np.array_equal(np.isnan(draws), np.isnan(ref))
+    assert idx == orc.choose(ref) == 321 and np.isnan(val)
+
+
+def test_not_positive_definite_raises_linalgerror(eng):
+    comp, cand, vals, hypers = synthetic_problem(50, 200, 3, 3, 24)
+    hypers[1, 2] = -1.0                      # negative amplitude -> K not PD at draw 1
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.ei_grid(comp, vals, cand, hypers)
+    draw, pivot = eng.not_pd_info()
+    assert draw == 1 and pivot == 0
+    with pytest.raises(np.linalg.LinAlgError):   # the oracle (scipy) raises at the same place
+        orc.ei_over_hypers(comp, cand, vals, hypers)
+    # the handle stays usable
+    hypers[1, 2] = 1.0
+    idx, _, _, _ = eng.ei_grid(comp, vals, cand, hypers)
+    assert idx == orc.choose(orc.ei_over_hypers(comp, cand, vals, hypers))
+
+
+def test_near_duplicate_observations(eng):
+    comp, cand, vals, hypers = synthetic_problem(120, 800, 4, 3, 25)
+    comp[60:] = comp[:60] + 1e-9             # pairs of (almost) identical observations
+    vals[60:] = vals[:60]
+    idx, _, _, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert_ei_close(draws, ref, rtol=1e-5)
+    assert idx == orc.choose(ref)
+
+
+def test_tail_values_keep_relative_accuracy(eng):
+    """EI spans hundreds of decades; Phi must come from erfc in the tail."""
+    comp, cand, vals, hypers = synthetic_problem(64, 2000, 2, 2, 26)
+    vals = vals - 40.0 * (np.arange(64) == 5)       # one very low observation -> best far below the mean
+    idx, _, _, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert ref[np.isfinite(ref)].min() < 1e-100
+    assert_ei_close(draws, ref, rtol=1e-6)
+    assert idx == orc.choose(ref)
+
+
+def test_chunking_and_draw_grouping_do_not_change_bits(eng):
+    comp, cand, vals, hypers = synthetic_problem(300, 3000, 6, 5, 27)
+    base = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    try:
+        eng.set_option("kstar_budget_bytes", 384 * 128 * 8)      # one 128-column tile, one draw at a time
+        small = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    finally:
+        eng.set_option("kstar_budget_bytes", 0)
+    assert small[0] == base[0] and np.array_equal(small[3], base[3]) and np.array_equal(small[2], base[2])
+
+
+def test_sharding_is_exact(eng):
+    """Two contiguous shards + the all-reduce rule == the single-GPU answer, bit for bit."""
+    comp, cand, vals, hypers = synthetic_problem(150, 2501, 5, 4, 28)
+    idx, val, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    recs, parts = [], []
+    eng.set_observations(comp, vals); eng.set_hypers(hypers); eng.factor()
+    for r in range(2):
+        lo, hi = sd.shard_bounds(cand.shape[0], 2, r)
+        eng.set_candidates(cand[lo:hi], index_base=lo)
+        eng.ei_run()
+        recs.append(list(eng.best()[::-1]))
+        parts.append(eng.ei_draws())
+    assert np.array_equal(np.vstack(parts), draws)
+    assert sd.pick_best(recs) == (idx, val)
+
+
+def test_gp_logprob(eng):
+    comp, cand, vals, hypers = synthetic_problem(180, 10, 4, 5, 29)
+    hypers[3, 2] = -2.0                      # not PD -> -inf, others finite
+    eng.set_observations(comp, vals); eng.set_hypers(hypers)
+    lp = eng.gp_logprob()
+    for h in range(5):
+        if h == 3:
+            assert lp[h] == -np.inf
+        else:
+            ref = orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:])
+            assert np.isclose(lp[h], ref, rtol=1e-10)
+
+
+def test_timings_are_reported(eng):
+    comp, cand, vals, hypers = synthetic_problem(256, 4000, 8, 3, 30)
+    eng.set_observations(comp, vals); eng.set_candidates(cand); eng.set_hypers(hypers)
+    eng.set_option("timing", 1)
+    eng.factor(); eng.ei_run()
+    tm = eng.timings()
+    eng.set_option("timing", 0)
+    assert tm["predict_gemm"][1] >= 1 and tm["predict_gemm"][0] > 0
+    assert tm["chol_diag"][1] == 256 // 64 and tm["factor_total"][1] == 1
+
+
+# ---- BASELINE.json full sizes: size-independent properties ---------------------------
+def test_c3_full_size_properties(eng):
+    """N_obs=2048, 32-D, 200k candidates, 20 draws (BASELINE config 3)."""
+    N, M, D, H = 2048, 200000, 32, 20
+    comp, cand, vals, hypers = synthetic_problem(N, M, D, H, 3000)
+    idx, val, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    # (1) MCMC mean / argmax: device result == numpy on the device's own EI matrix
+    assert np.array_equal(mean, np.mean(draws, axis=1))
+    assert idx == int(np.argmax(mean)) and val == mean[idx]
+    assert np.isfinite(draws).all() and (draws >= 0).all()
+    # (2) a candidate subsample against the CPU oracle (all 20 draws)
+    sub = np.r_[0:10, np.random.RandomState(0).choice(M, 490, replace=False), idx]
+    ref = orc.ei_over_hypers(comp, cand[sub], vals, hypers)
+    assert_ei_close(draws[sub], ref, rtol=1e-6)
+    # (3) per-candidate results do not depend on which other candidates share the launch
+    i2, _, _, d2 = eng.ei_grid(comp, vals, cand[sub], hypers, want_draws=True)
+    assert np.array_equal(d2, draws[sub])
+    assert sub[i2] == idx or mean[sub[i2]] == mean[idx]
+
+
+# ---- the plugin API end to end on the GPU --------------------------------------------
+def test_gpei_chooser_next_on_gpu_matches_reference(golden_dir, tmp_path):
+    """examples/braninpy through GPEIChooser.next: same seeded hypers, same job
+    as the reference's own run (tests/golden/branin_c1.npz)."""
+    from spearmint_amd.chooser import GPEIChooser
+    g = _g(golden_dir, "branin_c1.npz")
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=10")
+    npr.seed(int(g["seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert job == int(g["job"])
+    assert_ei_close(ch.last_overall_ei, g["ei"])
+
+
+def test_opt_and_persec_chooser_next_on_gpu(golden_dir, tmp_path):
+    from spearmint_amd.chooser import GPEIOptChooser, GPEIperSecChooser
+    g = _g(golden_dir, "chooser_next.npz")
+    args = (g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    ch = GPEIOptChooser.init(str(tmp_path / "a"), "mcmc_iters=4,burnin=6,grid_subset=5,use_multiprocessing=0")
+    os.makedirs(str(tmp_path / "a"), exist_ok=True)
+    npr.seed(int(g["opt_seed"]))
+    job = ch.next(*args)
+    assert isinstance(job, tuple) == bool(int(g["opt_is_new"]))
+    if isinstance(job, tuple):
+        assert job[0] == int(g["opt_index"]) and np.allclose(job[1], g["opt_point"], atol=1e-5)
+    os.makedirs(str(tmp_path / "b"), exist_ok=True)
+    ps = GPEIperSecChooser.init(str(tmp_path / "b"), "mcmc_iters=3,burnin=4,grid_subset=4,ref_compat=1")
+    npr.seed(int(g["ps_seed"]))
+    job = ps.next(*args)
+    if isinstance(job, tuple):
+        assert job[0] == int(g["ps_index"]) and np.allclose(job[1], g["ps_point"], atol=1e-5)
+    else:
+        assert job == int(g["ps_index"])

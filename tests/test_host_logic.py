@@ -1,0 +1,150 @@
+"""Host-side logic of the choosers on a CPU-only box: argument parsing, the
+slice sampler's RNG order, state pickles, and -- with the test-only
+OracleEngine injected in place of the GPU -- that a seeded .next() proposes
+exactly what the REFERENCE's own .next() proposed (tests/golden, produced by
+running the reference)."""
+import os
+import pickle
+
+import numpy as np
+import numpy.random as npr
+import pytest
+
+from spearmint_amd import hostgp, util
+from spearmint_amd.chooser import GPEIChooser, GPEIOptChooser, GPEIperSecChooser
+from tests.helpers import OracleEngine, np_mean_device_order
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_unpack_args():
+    assert util.unpack_args("mcmc_iters=20, noiseless = 1") == {"mcmc_iters": "20", "noiseless": "1"}
+    assert util.unpack_args("") == {}
+    assert util.unpack_args("x") == {}
+
+
+def test_slice_sampler_rng_order_matches_reference(golden_dir):
+    g = _g(golden_dir, "slice_sampler.npz")
+    comp, vals = g["comp"], g["vals"]
+
+    def lp_ls(ls):
+        if np.any(ls < 0) or np.any(ls > 2):
+            return -np.inf
+        return hostgp.data_logprob(comp, vals, 0.1, 1.3, 1e-3, ls)
+
+    assert np.isclose(lp_ls(np.ones(3)), float(g["lp_at_ones"]), rtol=1e-12)
+    npr.seed(77)
+    x = g["compwise"][0]
+    for k in range(1, g["compwise"].shape[0]):
+        x = util.slice_sample(x, lp_ls, compwise=True)
+        assert np.allclose(x, g["compwise"][k], rtol=1e-9)
+    npr.seed(78)
+    y = g["joint"][0]
+    for k in range(1, g["joint"].shape[0]):
+        y = util.slice_sample(y, lambda v: -0.5 * np.sum((v - 0.2) ** 2) / 0.3, compwise=False)
+        assert np.allclose(y, g["joint"][k], rtol=1e-9)
+
+
+def test_early_out_touches_nothing(tmp_path):
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=3")
+    grid = np.random.rand(10, 2)
+    assert ch.next(grid, np.zeros(10), np.zeros(10), np.arange(1, 10), np.array([], int), np.array([0])) == 1
+    assert ch._eng is None and ch.D == -1
+
+
+def test_gpei_next_matches_reference_c1(golden_dir, tmp_path):
+    """BASELINE config 1 through the plugin API: same hypers, same proposal."""
+    g = _g(golden_dir, "branin_c1.npz")
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=10")
+    eng = OracleEngine(); ch._eng = eng
+    npr.seed(int(g["seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert isinstance(job, int) and job == int(g["job"])
+    assert eng.calls == [("ei_grid", 980, 10)]
+    assert np.allclose(ch.last_overall_ei, g["ei"], rtol=1e-9, atol=1e-300)
+    # state pickle: same keys as the reference's (GPEIChooser.py:70-76)
+    ch.save_state()
+    st = pickle.load(open(ch.state_pkl, "rb"))
+    assert sorted(st) == ["amp2", "dims", "ls", "mean", "noise"]
+    assert np.allclose(np.concatenate(([st["mean"], st["noise"], st["amp2"]], st["ls"])), g["hypers"][-1], rtol=1e-9)
+    assert os.path.basename(ch.state_pkl).endswith("GPEIChooser.pkl")
+
+
+def test_gpei_restart_reloads_state(golden_dir, tmp_path):
+    g = _g(golden_dir, "branin_c1.npz")
+    a = GPEIChooser.init(str(tmp_path), "mcmc_iters=2")
+    a._eng = OracleEngine(); npr.seed(3)
+    a.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    a.save_state()
+    b = GPEIChooser.init(str(tmp_path), "mcmc_iters=2")
+    b._real_init(2, g["values"][g["complete"]])
+    assert np.array_equal(b.ls, a.ls) and b.amp2 == a.amp2 and b.noise == a.noise and b.mean == a.mean
+
+
+def test_opt_next_matches_reference(golden_dir, tmp_path):
+    g = _g(golden_dir, "chooser_next.npz")
+    ch = GPEIOptChooser.init(str(tmp_path), "mcmc_iters=4,burnin=6,grid_subset=5,use_multiprocessing=0")
+    eng = OracleEngine(); ch._eng = eng
+    npr.seed(int(g["opt_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert np.allclose(ch.hyper_rows(), g["opt_hypers"], rtol=1e-9)
+    assert [c[1] for c in eng.calls] == [len(g["candidates"]) + 10, len(g["candidates"]) + 5]
+    if int(g["opt_is_new"]):
+        assert isinstance(job, tuple) and job[0] == int(g["opt_index"])
+        assert np.allclose(job[1], g["opt_point"], atol=1e-6)
+    else:
+        assert job == int(g["opt_index"])
+    assert os.path.exists(ch.stats_file) and os.path.exists(ch.state_pkl)
+    assert "lsdata" in ch.generate_stats_html()
+    # pickling the chooser (multiprocessing / fork safety) drops the engine handle
+    clone = pickle.loads(pickle.dumps(ch))
+    assert clone._eng is None
+
+
+def test_persec_next_matches_reference_bug_compatible(golden_dir, tmp_path):
+    g = _g(golden_dir, "chooser_next.npz")
+    ch = GPEIperSecChooser.init(str(tmp_path), "mcmc_iters=3,burnin=4,grid_subset=4,ref_compat=1")
+    ch._eng = OracleEngine()
+    npr.seed(int(g["ps_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert np.allclose(ch._rows(ch.hyper_samples), g["ps_hypers"], rtol=1e-9)
+    assert np.allclose(ch._rows(ch.time_hyper_samples), g["ps_time_hypers"], rtol=1e-9)  # never cleared (:199)
+    if int(g["ps_is_new"]):
+        assert isinstance(job, tuple) and job[0] == int(g["ps_index"])
+        assert np.allclose(job[1], g["ps_point"], atol=1e-6)
+    else:
+        assert job == int(g["ps_index"])
+
+
+def test_persec_default_semantics_evaluate_all_draws(golden_dir, tmp_path):
+    g = _g(golden_dir, "chooser_next.npz")
+    ch = GPEIperSecChooser.init(str(tmp_path), "mcmc_iters=3,burnin=2,grid_subset=3")
+    eng = OracleEngine(); ch._eng = eng
+    npr.seed(1)
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert all(c[2] == 3 for c in eng.calls) and len(ch.time_hyper_samples) == 3
+    assert isinstance(job, (int, tuple))
+
+
+def test_pending_raises_clearly(golden_dir, tmp_path):
+    g = _g(golden_dir, "branin_c1.npz")
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=2")
+    ch._eng = OracleEngine(); npr.seed(0)
+    with pytest.raises(NotImplementedError):
+        ch.next(g["grid"], g["values"], g["durations"], g["candidates"][1:], g["candidates"][:1], g["complete"])
+
+
+def test_unsupported_covariance_rejected(tmp_path):
+    with pytest.raises(ValueError):
+        GPEIChooser.init(str(tmp_path), "covar=ARDSE")
+
+
+@pytest.mark.parametrize("H", [1, 3, 7, 8, 9, 10, 16, 20, 31, 128, 129, 300])
+def test_device_mean_order_is_numpys(H):
+    rs = np.random.RandomState(H)
+    a = rs.rand(50, H) * 10.0 ** rs.randint(-20, 3, size=(50, H))
+    want = np.mean(a, axis=1)
+    got = np.array([np_mean_device_order(r) for r in a])
+    assert np.array_equal(want, got)
