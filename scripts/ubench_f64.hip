@@ -18,8 +18,9 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, double seed)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
-            if (MODE != 1) acc[i] = MFMA(a, b, acc[i]);
-            if (MODE != 0) {
+            if (MODE == 3) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            else if (MODE != 1) acc[i] = MFMA(a, b, acc[i]);
+            if (MODE == 1 || MODE == 2) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = fma(v[q], a, b);
             }
@@ -46,7 +47,7 @@ void run(const char* name, int blocks_per_cu, double* d, int iters)
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double waves = (double)grid * 4;
     double mf = (MODE != 1) ? waves * iters * NACC * 2048.0 : 0;            // 16*16*4*2 per MFMA
-    double vf = (MODE != 0) ? waves * iters * NACC * 8 * 64 * 2.0 : 0;      // 8 FMA x 64 lanes
+    double vf = (MODE == 1 || MODE == 2) ? waves * iters * NACC * 8 * 64 * 2.0 : 0;      // 8 FMA x 64 lanes
     printf("%-28s blocks/CU=%d  %.3f ms  mfma %.1f TF  valu %.1f TF  total %.1f TF\n", name, blocks_per_cu,
            ms, mf / ms / 1e9, vf / ms / 1e9, (mf + vf) / ms / 1e9);
 }
@@ -58,6 +59,8 @@ int main()
         run<4, 0>("mfma only, 4 acc", b, d, 5000);
         run<8, 0>("mfma only, 8 acc", b, d, 2500);
         run<16, 0>("mfma only, 16 acc", b, d, 1250);
+        run<8, 3>("mfma VGPR acc (asm), 8 acc", b, d, 2500);
+        run<16, 3>("mfma VGPR acc (asm), 16 acc", b, d, 1250);
         run<8, 1>("valu fma only", b, d, 2500);
         run<8, 2>("mfma + 8 fma interleaved", b, d, 2500);
     }
