@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kstar-budget-mb", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0, help="0 = library default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,6 +130,8 @@ def main():
         eng.set_time_model(prob[4], prob[5])
     if args.kstar_budget_mb:
         eng.set_option("kstar_budget_bytes", args.kstar_budget_mb << 20)
+    if args.streams:
+        eng.set_option("streams", args.streams)
 
     def sync():
         if world > 1:

@@ -59,7 +59,7 @@ __device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ Lm, double* __restrict__ Dinv,
+__global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, double* __restrict__ Dinv,
                                                    int* __restrict__ info, int Np, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -146,7 +146,7 @@ void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np,
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ Lm,
+__global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
                                                     const double* __restrict__ Dinv, int Np, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -208,7 +208,7 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 // WT must be zero-initialised by the caller (entries above the block diagonal
 // inside a 128-wide GEMM row block are read by the predict GEMM).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trinv(const double* __restrict__ Lm,
+__global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
                                                const double* __restrict__ Dinv,
                                                double* __restrict__ WT, int Np)
 {

@@ -85,7 +85,7 @@ __device__ __forceinline__ double matern52_corr(double g, double s1, double s2)
 // MODE 2: cross-mean out[h][c] = exp( sum_j amp2*k[j][c]*alpha[h][j] + mean )
 // ---------------------------------------------------------------------------
 template <int MODE, int QC>
-__global__ __launch_bounds__(256) void k_cov(
+__global__ __launch_bounds__(256, 2) void k_cov(
     const double* __restrict__ Xs, const double* __restrict__ s1,
     const double* __restrict__ Cs, const double* __restrict__ s2,
     const double* __restrict__ htab, const double* __restrict__ alpha,

@@ -65,7 +65,10 @@ static const char* kStageNames[ST_COUNT] = {
 struct spx_handle {
     int device = 0;
     bool inited = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // main stream (also the only one the factorization uses)
+    hipStream_t stream2 = nullptr;   // second stream: EI work items alternate between the two so that
+                                     // one launch's tail overlaps the next launch's head
+    hipEvent_t ev_sync[4] = {nullptr, nullptr, nullptr, nullptr};
 
     int64_t N = 0, M = 0, index_base = 0;
     int D = 0, Dp = 0, Np = 0, H = 0;
@@ -74,13 +77,14 @@ struct spx_handle {
     int nmodels = 1;  // 1 = objective GP only, 2 = + log-duration GP
     double best = 0.0;
     int not_pd_draw = -1, not_pd_pivot = -1;
-    int64_t kst_budget = 128ll << 20;
+    int64_t kst_budget = 512ll << 20;   // K(X*,X) staging buffer per stream (bytes)
+    int nstreams = 1;
 
     std::vector<double> hyp_host, thyp_host;
 
     DevBuf comp, vals, ldur, cand, hyp, htab;
     DevBuf Xs, X2s, s1, Lm, WT, Dinv, gamma, alpha, info, lp;
-    DevBuf Cs, s2, Kst, part_ss, part_bg, time_m, ei_draw, ei_mean, mom_m, mom_v;
+    DevBuf Cs[2], s2[2], Kst[2], part_ss[2], part_bg[2], time_m[2], ei_draw, ei_mean, mom_m, mom_v;
     DevBuf am_val, am_idx, am_out_val, am_out_idx, scratch;
 
     double best_val = 0.0;
@@ -100,12 +104,14 @@ static int ensure_init(spx_handle* h)
     HIPCHK(hipSetDevice(h->device));
     if (!h->inited) {
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev_sync[i], hipEventDisableTiming));
         h->inited = true;
     }
     return SPX_OK;
 }
 
-static int ev_begin(spx_handle* h, int stage)
+static int ev_begin(spx_handle* h, int stage, hipStream_t strm)
 {
     if (!h->timing) return -1;
     if (h->ev_used == h->ev_pool.size()) {
@@ -115,12 +121,12 @@ static int ev_begin(spx_handle* h, int stage)
     }
     spx_handle::Ev& e = h->ev_pool[h->ev_used];
     e.stage = stage;
-    (void)hipEventRecord(e.a, h->stream);
+    (void)hipEventRecord(e.a, strm);
     return (int)h->ev_used++;
 }
-static void ev_end(spx_handle* h, int id)
+static void ev_end(spx_handle* h, int id, hipStream_t strm)
 {
-    if (id >= 0) (void)hipEventRecord(h->ev_pool[id].b, h->stream);
+    if (id >= 0) (void)hipEventRecord(h->ev_pool[id].b, strm);
 }
 static void ev_collect(spx_handle* h)
 {
@@ -133,12 +139,13 @@ static void ev_collect(spx_handle* h)
     }
     h->ev_used = 0;
 }
-#define TIMED(stage, stmt)                 \
-    do {                                   \
-        int ev_ = ev_begin(h, stage);      \
-        stmt;                              \
-        ev_end(h, ev_);                    \
+#define TIMED_S(stage, strm, stmt)              \
+    do {                                        \
+        int ev_ = ev_begin(h, stage, strm);     \
+        stmt;                                   \
+        ev_end(h, ev_, strm);                   \
     } while (0)
+#define TIMED(stage, stmt) TIMED_S(stage, h->stream, stmt)
 
 static int padded_dim(int D)
 {
@@ -176,14 +183,18 @@ void spx_destroy(spx_handle* h)
     if (h->inited) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->stream2);
         DevBuf* bufs[] = {&h->comp, &h->vals, &h->ldur, &h->cand, &h->hyp, &h->htab, &h->Xs, &h->X2s,
                           &h->s1, &h->Lm, &h->WT, &h->Dinv, &h->gamma, &h->alpha, &h->info, &h->lp,
-                          &h->Cs, &h->s2, &h->Kst, &h->part_ss, &h->part_bg, &h->time_m, &h->ei_draw,
-                          &h->ei_mean, &h->mom_m, &h->mom_v, &h->am_val, &h->am_idx, &h->am_out_val,
-                          &h->am_out_idx, &h->scratch};
+                          &h->Cs[0], &h->s2[0], &h->Kst[0], &h->part_ss[0], &h->part_bg[0], &h->time_m[0],
+                          &h->Cs[1], &h->s2[1], &h->Kst[1], &h->part_ss[1], &h->part_bg[1], &h->time_m[1],
+                          &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->am_val, &h->am_idx,
+                          &h->am_out_val, &h->am_out_idx, &h->scratch};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(h->ev_sync[i]);
         (void)hipStreamDestroy(h->stream);
+        (void)hipStreamDestroy(h->stream2);
     }
     delete h;
 }
@@ -192,7 +203,11 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
 {
     if (!h || !name) return fail(SPX_ERR_ARG, "spx_set_option: null");
     if (!strcmp(name, "kstar_budget_bytes")) {
-        h->kst_budget = value > 0 ? value : (128ll << 20);
+        h->kst_budget = value > 0 ? value : (512ll << 20);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "streams")) {  // 1 = everything on one stream (default), 2 = alternate EI work items
+        h->nstreams = value == 2 ? 2 : 1;
         return SPX_OK;
     }
     if (!strcmp(name, "timing")) {  // per-launch HIP events on the handle's stream; (re)starts the accumulators
@@ -385,6 +400,9 @@ static void plan_chunks(const spx_handle* h, int64_t* Mc, int* Hb)
     mc = mc / SPX_BN * SPX_BN;
     if (mc < SPX_BN) mc = SPX_BN;
     if (mc > Mp) mc = Mp;
+    // equal-sized chunks (no tiny, inefficient last launch)
+    const int64_t nchunks = (Mp + mc - 1) / mc;
+    mc = round_up((Mp + nchunks - 1) / nchunks, SPX_BN);
     int64_t hb = h->kst_budget / (8ll * h->Np * mc);
     if (hb < 1) hb = 1;
     if (hb > h->H) hb = h->H;
@@ -409,14 +427,21 @@ int spx_ei_run(spx_handle* h, int32_t flags)
     int64_t Mc; int Hb;
     plan_chunks(h, &Mc, &Hb);
 
-    if ((rc = h->Cs.reserve((size_t)Hb * Mc * Dp * 8))) return rc;
-    if ((rc = h->s2.reserve((size_t)Hb * Mc * 8))) return rc;
-    if ((rc = h->Kst.reserve((size_t)Hb * Np * Mc * 8))) return rc;
-    if ((rc = h->part_ss.reserve((size_t)nrb * Hb * Mc * 8))) return rc;
-    if ((rc = h->part_bg.reserve((size_t)nrb * Hb * Mc * 8))) return rc;
+    const int ns = h->nstreams;
+    for (int b = 0; b < 2; ++b) {
+        // scaled candidates (all draws) and predicted durations are double-buffered by chunk parity,
+        // the K(X*,X) staging buffer and the partial sums by stream
+        if ((rc = h->Cs[b].reserve((size_t)H * Mc * Dp * 8))) return rc;
+        if ((rc = h->s2[b].reserve((size_t)H * Mc * 8))) return rc;
+        if (per_sec && (rc = h->time_m[b].reserve((size_t)H * Mc * 8))) return rc;
+        if (b < ns) {
+            if ((rc = h->Kst[b].reserve((size_t)Hb * Np * Mc * 8))) return rc;
+            if ((rc = h->part_ss[b].reserve((size_t)nrb * Hb * Mc * 8))) return rc;
+            if ((rc = h->part_bg[b].reserve((size_t)nrb * Hb * Mc * 8))) return rc;
+        }
+    }
     if ((rc = h->ei_draw.reserve((size_t)H * Mp * 8))) return rc;
     if ((rc = h->ei_mean.reserve((size_t)Mp * 8))) return rc;
-    if (per_sec && (rc = h->time_m.reserve((size_t)Hb * Mc * 8))) return rc;
     if (keep_mom) {
         if ((rc = h->mom_m.reserve((size_t)H * Mp * 8))) return rc;
         if ((rc = h->mom_v.reserve((size_t)H * Mp * 8))) return rc;
@@ -437,33 +462,52 @@ int spx_ei_run(spx_handle* h, int32_t flags)
 
     const double* ls = h->hyp.d() + 3;
     const size_t nn = (size_t)Np * Np;
-    for (int64_t c0 = 0; c0 < Mp; c0 += Mc) {
+    hipStream_t strm[2] = {h->stream, ns == 2 ? h->stream2 : h->stream};
+    int item = 0, chunk = 0;
+    for (int64_t c0 = 0; c0 < Mp; c0 += Mc, ++chunk) {
         const int mc = (int)std::min<int64_t>(Mc, Mp - c0);       // multiple of 128
         const int64_t nreal = std::min<int64_t>(mc, M - c0);      // real candidates in the chunk
         const double* xc = h->cand.d() + (size_t)c0 * D;
-        for (int h0 = 0; h0 < H; h0 += Hb) {
-            const int nhb = std::min(Hb, H - h0);
-            if (per_sec) {
-                const int t0i = H + h0;
-                TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls + (size_t)t0i * hs, hs, nhb, 2.0,
-                                                  h->Cs.d(), h->s2.d()));
-                TIMED(ST_CROSS_MEAN, launch_cross_mean(s, h->Xs.d() + (size_t)t0i * Np * Dp, h->s1.d() + (size_t)t0i * Np,
-                                                       h->Cs.d(), h->s2.d(), h->htab.d() + (size_t)t0i * SPX_HT,
-                                                       h->alpha.d() + (size_t)t0i * Np, h->time_m.d(), (int)N, Np, mc, Dp, nhb));
-            }
-            TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls + (size_t)h0 * hs, hs, nhb, 2.0,
-                                              h->Cs.d(), h->s2.d()));
-            TIMED(ST_COV_CROSS, launch_cov_cross(s, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
-                                                 h->Cs.d(), h->s2.d(), h->htab.d() + (size_t)h0 * SPX_HT,
-                                                 h->Kst.d(), (int)N, Np, mc, Dp, nhb));
-            TIMED(ST_PREDICT_GEMM, launch_predict_gemm(s, h->WT.d() + (size_t)h0 * nn, h->Kst.d(),
-                                                       h->gamma.d() + (size_t)h0 * Np, h->part_ss.d(), h->part_bg.d(),
-                                                       Np, mc, nhb));
-            TIMED(ST_EI_FINALIZE, launch_ei_finalize(s, h->part_ss.d(), h->part_bg.d(), h->htab.d() + (size_t)h0 * SPX_HT,
-                                                     per_sec ? h->time_m.d() : nullptr, h->best, h->ei_draw.d(),
-                                                     keep_mom ? h->mom_m.d() : nullptr, keep_mom ? h->mom_v.d() : nullptr,
-                                                     nrb, mc, nhb, c0, M, Mp, h0));
+        const int par = chunk & 1;
+        double* Cs = h->Cs[par].d();
+        double* s2 = h->s2[par].d();
+        double* tm = per_sec ? h->time_m[par].d() : nullptr;
+        // the buffers of this parity were last read two chunks ago by work on the second stream
+        if (ns == 2 && chunk >= 2) HIPCHK(hipStreamWaitEvent(s, h->ev_sync[2 + par], 0));
+        if (per_sec) {
+            // log-duration GP: predicted duration of every candidate of the chunk, all draws in one launch
+            TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls + (size_t)H * hs, hs, H, 2.0, Cs, s2));
+            TIMED(ST_CROSS_MEAN, launch_cross_mean(s, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np, Cs, s2,
+                                                   h->htab.d() + (size_t)H * SPX_HT, h->alpha.d() + (size_t)H * Np, tm,
+                                                   (int)N, Np, mc, Dp, H));
         }
+        // 2 * cand / ls and |cand / ls|^2 for every draw (one launch per chunk)
+        TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls, hs, H, 2.0, Cs, s2));
+        if (ns == 2) {
+            HIPCHK(hipEventRecord(h->ev_sync[par], s));
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_sync[par], 0));
+        }
+        for (int h0 = 0; h0 < H; h0 += Hb, ++item) {
+            const int nhb = std::min(Hb, H - h0);
+            const int k = (ns == 2) ? (item & 1) : 0;
+            hipStream_t sk = strm[k];
+            TIMED_S(ST_COV_CROSS, sk, launch_cov_cross(sk, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
+                                                       Cs + (size_t)h0 * mc * Dp, s2 + (size_t)h0 * mc,
+                                                       h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb));
+            TIMED_S(ST_PREDICT_GEMM, sk, launch_predict_gemm(sk, h->WT.d() + (size_t)h0 * nn, h->Kst[k].d(),
+                                                             h->gamma.d() + (size_t)h0 * Np, h->part_ss[k].d(),
+                                                             h->part_bg[k].d(), Np, mc, nhb));
+            TIMED_S(ST_EI_FINALIZE, sk, launch_ei_finalize(sk, h->part_ss[k].d(), h->part_bg[k].d(),
+                                                           h->htab.d() + (size_t)h0 * SPX_HT,
+                                                           per_sec ? tm + (size_t)h0 * mc : nullptr, h->best,
+                                                           h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
+                                                           keep_mom ? h->mom_v.d() : nullptr, nrb, mc, nhb, c0, M, Mp, h0));
+        }
+        if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[2 + par], h->stream2));
+    }
+    if (ns == 2) {  // join: the reduction below needs every EI value
+        HIPCHK(hipEventRecord(h->ev_sync[0], h->stream2));
+        HIPCHK(hipStreamWaitEvent(s, h->ev_sync[0], 0));
     }
     TIMED(ST_MEAN_ARGMAX, {
         launch_mean_over_draws(s, h->ei_draw.d(), h->ei_mean.d(), M, Mp, H);
