@@ -25,7 +25,7 @@
 // C[i][c] = sum_{j <= i-block end} WT[j][i] * Kst[j][c]
 //   tile 128(i) x 128(c), 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles,
 //   K loop over j in steps of 16, register-staged double-buffered LDS.
-// Grid: 1-D, heaviest row blocks (largest ib = longest K loop) first.
+// Grid: 1-D, XCD-aware (see the block -> tile map below), heaviest row blocks first.
 // part_ss / part_bg: [nrb][nh][Mc]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_predict_gemm(
@@ -42,12 +42,22 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(
     const int g = lane >> 4, li = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int per_rb = ncb * nh;
-    const int bid = blockIdx.x;
-    const int ib = nrb - 1 - bid / per_rb;
-    const int rem = bid % per_rb;
-    const int h = rem / ncb;
-    const int cb = rem % ncb;
+    // Block -> tile map, XCD-aware.  Workgroup b is dispatched to XCD b % 8 (each XCD
+    // has a private 4 MiB L2).  All row blocks ib of one candidate tile (h, cb) read the
+    // same K* columns, so they are given to the same XCD (cb % 8 == xcd), and row blocks
+    // are issued strictly longest-K-loop-first inside every XCD: that order is what
+    // bounds the tail of the launch.  (Measured alternatives that co-schedule the row
+    // blocks of a tile to share K* in L2 cut FETCH_SIZE by 9-37 % but lengthen the
+    // launch by 1.5-8 %: the kernel is MFMA-bound, not fabric-bound -- DESIGN.md.)
+    const int ncbx = (ncb + 7) >> 3;               // candidate tiles per XCD
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int per_rb = ncbx * nh;
+    const int ib = nrb - 1 - slot / per_rb;
+    const int rem = slot % per_rb;
+    const int h = rem / ncbx;
+    const int cb = (rem % ncbx) * 8 + xcd;
+    if (cb >= ncb) return;                          // uniform per workgroup
 
     const double* Ag = WT + (size_t)h * Np * Np + (size_t)ib * BM;
     const double* Bg = Kst + (size_t)h * Np * Mc + (size_t)cb * BN;
@@ -171,7 +181,8 @@ void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, con
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_predict_gemm, dim3(ncb * nrb * nh), dim3(256), lds, s, WT, Kst, gamma,
+    const int grid = 8 * ((ncb + 7) / 8) * nrb * nh;
+    hipLaunchKernelGGL(k_predict_gemm, dim3(grid), dim3(256), lds, s, WT, Kst, gamma,
                        part_ss, part_bg, Np, Mc, nh, ncb, nrb);
 }
 
