@@ -55,6 +55,21 @@ WORKLOADS = {
                desc="C5 shard: GPEIperSec dual GP, 16D, N_obs=1024, 62.5k candidates/GPU (500k over 8), mcmc_iters=20"),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD CDNA4 spec; = vector fp64 peak)
+FP64_MFMA_MEASURED_TFLOPS = 77.5  # scripts/ubench_f64.hip on this pool: v_mfma_f64_16x16x4_f64, VGPR accumulators
+
+
+def pmc_traffic(workload):
+    """HBM bytes per k_predict_gemm launch from the committed rocprofv3 PMC passes of this
+    same command (profiles/r01_<workload>_rocprof_summary.json, written by
+    scripts/pmc_summary.py: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE
+    doubled per the gfx950 correction of MI355X_MICROARCH.md).  None when no profile exists."""
+    path = os.path.join(ROOT, "profiles", "r01_%s_rocprof_summary.json" % workload)
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["kernels"]["k_predict_gemm"]
+        return float(k["hbm_bytes_per_launch_corrected"]), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(w, seconds_hint=15.0):
@@ -89,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kstar-budget-mb", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="0 = library default")
+    ap.add_argument("--host-inclusive", action="store_true",
+                    help="also time the one-shot host-buffer entry point (PCIe H2D/D2H included)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,11 +121,20 @@ def main():
     except ImportError:
         if world > 1:
             raise
+    # Test hooks (not used by the driver): SPX_BENCH_BACKEND=gloo exercises the N > 1 code path
+    # on a box where RCCL cannot run (e.g. two ranks sharing the single GPU of a dev box, with
+    # SPX_BENCH_SINGLE_DEVICE=1); the default is "nccl" == RCCL over xGMI, one GPU per rank.
+    backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")
+    if os.environ.get("SPX_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as tdist
-        torch.cuda.set_device(local_rank)
-        tdev = torch.device("cuda", local_rank)
-        tdist.init_process_group(backend="nccl", device_id=tdev)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            tdev = torch.device("cuda", local_rank)
+            tdist.init_process_group(backend="nccl", device_id=tdev)
+        else:
+            tdist.init_process_group(backend=backend)
 
     w = WORKLOADS[args.workload]
     N, M, D, H = w["N"], w["M"], w["D"], w["H"]
@@ -155,7 +181,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev if tdev is not None else "cpu")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -170,9 +196,11 @@ def main():
         avg_s = gemm_ms / gemm_n * 1e-3
         evals_per_launch = evals_per_step * args.steps / gemm_n
         achieved = flops_per_eval * evals_per_launch / avg_s / 1e12
+        traffic, traffic_src = pmc_traffic(args.workload) if world == 1 else (None, None)
         roofline = {"bound": "mfma", "kernel": "k_predict_gemm", "achieved": achieved,
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_source": traffic_src, "peak_measured_ubench": FP64_MFMA_MEASURED_TFLOPS,
                     "launches": gemm_n, "avg_launch_ms": gemm_ms / gemm_n,
                     "flops_per_eval": flops_per_eval, "evals_per_launch": evals_per_launch,
                     "dtype_peak_source": "AMD MI355X spec: 78.6 TFLOP/s fp64 matrix"}
@@ -192,6 +220,10 @@ def main():
             "stages_ms_per_step": {k: v[0] / args.steps for k, v in tm.items() if v[1]},
             "best_index": best[0], "best_ei": best[1],
         }
+        if world == 1 and args.host_inclusive and not w["per_sec"]:
+            t0 = time.perf_counter()
+            eng.ei_grid(comp, vals, shard, hypers, want_mean=False)
+            out["host_inclusive_value"] = evals_per_step / (time.perf_counter() - t0)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
