@@ -93,11 +93,20 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
     __syncthreads();
 
     if (wave == 0) {
-        // --- unblocked Cholesky of S, lane i owns row i ---------------------
+        // --- unblocked Cholesky of S: lane i keeps row i in registers (fully unrolled,
+        // static register indices); column j is scaled by 1/sqrt(pivot) and the trailing
+        // update a[i][kc] -= l_ij * l_kc,j takes l_kc,j from lane kc with v_readlane.
+        // Entries above the diagonal are updated too (no predicate) but never read.
+        // (A ds_bpermute/__shfl variant and sched_group_barrier pipelining were tried:
+        // hipcc then demotes the row array to scratch; this form measured fastest.)
         const int i = lane;
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = S[i * LDS_S + c];
         int bad = 0;
+#pragma unroll
         for (int j = 0; j < NB; ++j) {
-            double d = S[j * LDS_S + j];
+            double d = readlane_f64(a[j], j);
             if (!(d > 0.0)) {  // also catches NaN, like LAPACK dpotrf's (ajj <= 0 || isnan)
                 if (!bad) bad = (int)kb0 + j + 1;
                 d = 1.0;
@@ -105,29 +114,33 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
             const double sd = sqrt(d);
             const double rinv = 1.0 / sd;
             double lij = 0.0;
-            if (i > j) lij = S[i * LDS_S + j] * rinv;
+            if (i > j) lij = a[j] * rinv;
             else if (i == j) lij = sd;
-            S[i * LDS_S + j] = lij;
+            a[j] = lij;
+#pragma unroll
             for (int kc = j + 1; kc < NB; ++kc) {
                 const double lk = readlane_f64(lij, kc);
-                if (i >= kc) S[i * LDS_S + kc] -= lij * lk;
+                a[kc] -= lij * lk;
             }
         }
         if (bad && lane == 0) {
             if (info[h] == 0) info[h] = bad;
         }
-        // --- X = L_kk^-1, lane c owns column c -------------------------------
+#pragma unroll
+        for (int c = 0; c < NB; ++c) S[i * LDS_S + c] = (c <= i) ? a[c] : 0.0;
+        // --- X = L_kk^-1 by forward substitution: lane c keeps column c of X in registers,
+        // L[r][p] is a wave-uniform (broadcast) LDS read that does not depend on X.
         const int c = lane;
+        double x[NB];
+#pragma unroll
         for (int r = 0; r < NB; ++r) {
-            double a = (r == c) ? 1.0 : 0.0;
-            for (int p = 0; p < r; ++p) {
-                const double lrp = S[r * LDS_S + p];           // broadcast
-                const double xp = X[p * LDS_S + c];            // own column (0 above the diagonal)
-                a -= lrp * xp;
-            }
-            const double x = (r >= c) ? a / S[r * LDS_S + r] : 0.0;
-            X[r * LDS_S + c] = x;
+            double acc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int p = 0; p < r; ++p) acc -= S[r * LDS_S + p] * x[p];
+            x[r] = (r >= c) ? acc / S[r * LDS_S + r] : 0.0;
         }
+#pragma unroll
+        for (int r = 0; r < NB; ++r) X[r * LDS_S + c] = x[r];
     }
     __syncthreads();
     // write L_kk (upper part zero) and its inverse
