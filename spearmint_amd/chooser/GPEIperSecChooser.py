@@ -102,6 +102,7 @@ class GPEIperSecChooser(GPEIBase):
             raise NotImplementedError("pending-experiment fantasies (GPEIperSecChooser.py:492-548) "
                                       "are not on the GPU path yet")
         rows, trows = self._paired_samples()
+        self._lp_key = None
         idx, val, mean, draws = self.engine().ei_per_sec_grid(comp, vals, durs, cand, rows, trows,
                                                               want_mean=True, want_draws=False)
         if self.ref_compat:

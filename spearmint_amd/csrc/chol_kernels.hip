@@ -338,6 +338,68 @@ void launch_alpha(hipStream_t s, const double* WT, const double* gamma, double* 
     hipLaunchKernelGGL(k_alpha, dim3(Np / 4, nh), dim3(256), 0, s, WT, gamma, alpha, Np);
 }
 
+// ---------------------------------------------------------------------------
+// gamma = L^-1 (vals - mean) by blocked forward substitution, one workgroup per draw:
+//   gamma_k = Dinv_k ( r_k - sum_{p<k} L_kp gamma_p )
+// Used by the lean log-likelihood path (no W = L^-1 needed).  Wave w owns rows
+// 16 w .. 16 w + 15 of the block row; lanes run along the columns (coalesced 512 B
+// row segments) and a shuffle tree reduces each row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_solve(const double* __restrict__ Lm,
+                                                   const double* __restrict__ Dinv,
+                                                   const double* __restrict__ vals,
+                                                   const double* __restrict__ htab,
+                                                   double* __restrict__ gamma, int N, int Np)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* gam = smem;        // [Np]
+    double* tvec = smem + Np;  // [64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.x;
+    const int nblk = Np / NB;
+    const double* Lh = Lm + (size_t)h * Np * Np;
+    const double* Dh = Dinv + (size_t)h * nblk * NB * NB;
+    const double mean = htab[h * SPX_HT + 0];
+    for (int k = 0; k < nblk; ++k) {
+        const size_t kb0 = (size_t)k * NB;
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = 16 * wave + rr;
+            const double* Lr = Lh + (kb0 + row) * Np;
+            double acc = 0.0;
+            for (int cidx = lane; cidx < (int)kb0; cidx += 64) acc += Lr[cidx] * gam[cidx];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0) {
+                const int gi = (int)kb0 + row;
+                const double r = (gi < N) ? (vals[gi] - mean) : 0.0;
+                tvec[row] = r - acc;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < NB) {
+            const double* Dr = Dh + (size_t)k * NB * NB + threadIdx.x * NB;
+            double acc = 0.0;
+            for (int q = 0; q <= (int)threadIdx.x; ++q) acc += Dr[q] * tvec[q];
+            gam[kb0 + threadIdx.x] = acc;
+            gamma[(size_t)h * Np + kb0 + threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_fwd_solve(hipStream_t s, const double* L, const double* Dinv, const double* vals,
+                      const double* htab, double* gamma, int N, int Np, int nh)
+{
+    const size_t lds = (size_t)(Np + NB) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_solve),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_fwd_solve, dim3(nh), dim3(256), lds, s, L, Dinv, vals, htab, gamma, N, Np);
+}
+
 // lp = -sum log diag(L) - 0.5 |gamma|^2   (GPEIChooser.py:284); -inf if not PD
 __global__ __launch_bounds__(256) void k_logprob(const double* __restrict__ Lm,
                                                  const double* __restrict__ gamma,

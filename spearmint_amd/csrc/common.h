@@ -45,6 +45,8 @@ void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT
 void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
                   double* gamma, int N, int Np, int nh);
 void launch_alpha(hipStream_t s, const double* WT, const double* gamma, double* alpha, int Np, int nh);
+void launch_fwd_solve(hipStream_t s, const double* L, const double* Dinv, const double* vals,
+                      const double* htab, double* gamma, int N, int Np, int nh);
 void launch_logprob(hipStream_t s, const double* L, const double* gamma, const int* info,
                     double* out, int Np, int nh);
 

@@ -287,14 +287,15 @@ int spx_set_time_model(spx_handle* h, const double* log_durs, const double* time
 }
 
 // ---------------------------------------------------------------------------
-static int do_factor(spx_handle* h, bool tolerate_not_pd)
+static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
 {
     if (!h->have_obs || !h->have_hyp)
         return fail(SPX_ERR_ARG, "spx_factor: observations and hypers must be set first");
     int rc = ensure_init(h);
     if (rc) return rc;
-    const int nm = h->have_time ? 2 : 1;
-    h->nmodels = nm;
+    // lean: objective GP only, Cholesky + forward solve, no W = L^-1 (log-likelihood path)
+    const int nm = (h->have_time && !lean) ? 2 : 1;
+    if (!lean) h->nmodels = nm;
     const int H = h->H, nh = nm * H, D = h->D, Dp = h->Dp, Np = h->Np;
     const int64_t N = h->N;
     const int nblk = Np / SPX_NB;
@@ -319,7 +320,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd)
     if ((rc = h->X2s.reserve((size_t)nh * Np * Dp * 8))) return rc;
     if ((rc = h->s1.reserve((size_t)nh * Np * 8))) return rc;
     if ((rc = h->Lm.reserve(nn * 8))) return rc;
-    if ((rc = h->WT.reserve(nn * 8))) return rc;
+    if (!lean && (rc = h->WT.reserve(nn * 8))) return rc;
     if ((rc = h->Dinv.reserve((size_t)nh * nblk * SPX_NB * SPX_NB * 8))) return rc;
     if ((rc = h->gamma.reserve((size_t)nh * Np * 8))) return rc;
     if ((rc = h->alpha.reserve((size_t)nh * Np * 8))) return rc;
@@ -334,7 +335,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd)
     HIPCHK(hipMemcpyAsync(h->htab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(t0, s));
     HIPCHK(hipMemsetAsync(h->info.p, 0, (size_t)nh * sizeof(int), s));
-    HIPCHK(hipMemsetAsync(h->WT.p, 0, nn * 8, s));
+    if (!lean) HIPCHK(hipMemsetAsync(h->WT.p, 0, nn * 8, s));
 
     const double* ls = h->hyp.d() + 3;
     TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d()));
@@ -345,13 +346,17 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd)
         TIMED(ST_CHOL_DIAG, launch_chol_diag(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, Np, k, nh));
         if (k + 1 < nblk) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh));
     }
-    TIMED(ST_TRINV, launch_trinv(s, h->Lm.d(), h->Dinv.d(), h->WT.d(), Np, nh));
-    TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d(), h->vals.d(), h->htab.d(), h->gamma.d(), (int)N, Np, H));
-    if (nm == 2)
-        TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d() + (size_t)H * Np * Np, h->ldur.d(),
-                                            h->htab.d() + (size_t)H * SPX_HT,
-                                            h->gamma.d() + (size_t)H * Np, (int)N, Np, H));
-    TIMED(ST_GAMMA_ALPHA, launch_alpha(s, h->WT.d(), h->gamma.d(), h->alpha.d(), Np, nh));
+    if (lean) {
+        TIMED(ST_GAMMA_ALPHA, launch_fwd_solve(s, h->Lm.d(), h->Dinv.d(), h->vals.d(), h->htab.d(), h->gamma.d(), (int)N, Np, H));
+    } else {
+        TIMED(ST_TRINV, launch_trinv(s, h->Lm.d(), h->Dinv.d(), h->WT.d(), Np, nh));
+        TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d(), h->vals.d(), h->htab.d(), h->gamma.d(), (int)N, Np, H));
+        if (nm == 2)
+            TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d() + (size_t)H * Np * Np, h->ldur.d(),
+                                                h->htab.d() + (size_t)H * SPX_HT,
+                                                h->gamma.d() + (size_t)H * Np, (int)N, Np, H));
+        TIMED(ST_GAMMA_ALPHA, launch_alpha(s, h->WT.d(), h->gamma.d(), h->alpha.d(), Np, nh));
+    }
     HIPCHK(hipEventRecord(t1, s));
     std::vector<int> info(nh);
     HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)nh * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -368,7 +373,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd)
     h->not_pd_draw = h->not_pd_pivot = -1;
     for (int i = 0; i < nh; ++i)
         if (info[i]) { h->not_pd_draw = i; h->not_pd_pivot = info[i] - 1; break; }
-    h->factored = true;
+    h->factored = !lean;
     h->ran = false;
     if (h->not_pd_draw >= 0 && !tolerate_not_pd) {
         h->factored = false;
@@ -637,16 +642,12 @@ int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, doubl
 int spx_gp_logprob(spx_handle* h, double* out)
 {
     if (!h || !out) return fail(SPX_ERR_ARG, "spx_gp_logprob: null");
-    const bool had_time = h->have_time;
-    h->have_time = false;  // data term of the objective GP only
-    int rc = do_factor(h, true);
-    h->have_time = had_time;
+    int rc = do_factor(h, true, true);   // K(X,X), Cholesky, forward solve -- no inverse
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
     launch_logprob(h->stream, h->Lm.d(), h->gamma.d(), (const int*)h->info.p, h->lp.d(), h->Np, h->H);
     HIPCHK(hipMemcpyAsync(out, h->lp.p, (size_t)h->H * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->not_pd_draw >= 0 || had_time) h->factored = false;  // force a clean spx_factor before EI
     return SPX_OK;
 }
 

@@ -267,9 +267,17 @@ class Engine(object):
         self._check(self._lib.spx_get_moments(self._h, int(draw), _dp(m), _dp(v)))
         return m, v
 
-    def gp_logprob(self):
+    def gp_logprob(self, raise_not_pd=False):
+        """Data term of the GP log posterior for every resident draw
+        (-sum log diag L - 0.5 r' K^-1 r, GPEIChooser.py:281-285); -inf where the
+        covariance is not positive definite, or LinAlgError if raise_not_pd
+        (what spla.cholesky does inside the reference's logprob closures)."""
         out = np.empty(self.H)
         self._check(self._lib.spx_gp_logprob(self._h, _dp(out)))
+        if raise_not_pd:
+            draw, pivot = self.not_pd_info()
+            if draw >= 0:
+                raise LinAlgError("%d-th leading minor of the array is not positive definite" % (pivot + 1))
         return out
 
     def not_pd_info(self):

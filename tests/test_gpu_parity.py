@@ -309,3 +309,34 @@ def test_opt_and_persec_chooser_next_on_gpu(golden_dir, tmp_path):
         assert job[0] == int(g["ps_index"]) and np.allclose(job[1], g["ps_point"], atol=1e-5)
     else:
         assert job == int(g["ps_index"])
+
+
+def test_sampler_with_gpu_loglikelihood_matches_reference(golden_dir, tmp_path):
+    """the slice sampler's log-likelihood on the GPU
+    (spx_gp_logprob: K build + Cholesky + forward solve per call).  Same seeded
+    RNG stream, so the hyper draws and the proposal must equal the reference's."""
+    from spearmint_amd.chooser import GPEIChooser
+    g = _g(golden_dir, "branin_c1.npz")
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=10,gpu_logprob=1")
+    npr.seed(int(g["seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert job == int(g["job"])
+    assert np.allclose(np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)), g["hypers"][-1], rtol=1e-6)
+    assert_ei_close(ch.last_overall_ei, g["ei"], rtol=1e-5)
+
+
+def test_gpu_loglikelihood_large_n_and_not_pd(eng):
+    comp, cand, vals, hypers = synthetic_problem(700, 10, 6, 3, 31)
+    eng.set_observations(comp, vals); eng.set_hypers(hypers)
+    lp = eng.gp_logprob()
+    for h in range(3):
+        ref = orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:])
+        assert np.isclose(lp[h], ref, rtol=1e-11)
+    hypers[0, 2] = -1.0
+    eng.set_hypers(hypers)
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.gp_logprob(raise_not_pd=True)
+    # a logprob call must not leave a stale factorisation behind for the EI path
+    eng.set_candidates(cand)
+    with pytest.raises(ValueError):
+        eng.ei_run()
