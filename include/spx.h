@@ -85,6 +85,16 @@ int spx_set_time_model(spx_handle* h, const double* log_durs,
  * GPEIChooser.py:186,190), factor it (:191), and form what the solves need
  * (:194).  Returns SPX_ERR_NOT_PD like spla.cholesky raising LinAlgError.     */
 int spx_factor(spx_handle* h);
+/* Pending-experiment fantasies (GPEIChooser.py:209-266; "next" row 2 of SURVEY 8(f)).
+ * Call after spx_set_observations was given comp_pend = [comp; pend] (n = N + P rows; the
+ * vals argument is then only a placeholder) and spx_factor has run:
+ *   fant  H x n x S, per draw row-major [i][s]: fant_vals of :245-246 (tile(vals) on top of
+ *         pend_fant);   bests H x S: np.min(fant_vals, axis=0) (:249).   1 <= S <= 128.
+ * The next spx_ei_run scores every candidate against every fantasy (:253-263) and averages
+ * over S in numpy's summation order (:265).  NULL / S = 0 clears; so does any call that
+ * invalidates the factorisation.                                                      */
+int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, int32_t S);
+
 /* Hot path, stage 2: K(X*,X) (:187), triangular solve (:195), predictive
  * mean/variance (:198-199), EI (:202-206) for every (candidate, draw); then the
  * MCMC mean and the argmax (:153).  Results stay on the device.               */

@@ -173,6 +173,24 @@ def compute_ei_pending(comp, pend, cand, vals, hyper, randn_ps):
     return np.mean(ei, axis=1)
 
 
+def compute_ei_fantasies(comp_pend, cand, hyper, fant_vals, bests):
+    """Second half of the pending branch (GPEIChooser.py:251-266) for given
+    fantasy values: EI of every candidate against every fantasy, averaged."""
+    mean, noise, amp2, ls = unpack_hyper(hyper)
+    cp_cov = cov(amp2, ls, comp_pend) + noise * np.eye(comp_pend.shape[0])
+    cp_chol = spla.cholesky(cp_cov, lower=True)
+    cand_cross = cov(amp2, ls, comp_pend, cand)
+    alpha = spla.cho_solve((cp_chol, True), fant_vals - mean)
+    beta = spla.solve_triangular(cp_chol, cand_cross, lower=True)
+    func_m = np.dot(cand_cross.T, alpha) + mean
+    func_v = amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        func_s = np.sqrt(func_v[:, np.newaxis])
+        u = (bests[np.newaxis, :] - func_m) / func_s
+        ei = func_s * (u * sps.norm.cdf(u) + sps.norm.pdf(u))
+    return np.mean(ei, axis=1)
+
+
 # --------------------------------------------------------------------------
 # EI per second  (S/chooser/GPEIperSecChooser.py:437-491)
 # --------------------------------------------------------------------------

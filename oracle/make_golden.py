@@ -22,6 +22,7 @@ Fixtures (all float64, ref = the reference's own functions):
                    slice-sampled hypers of each draw, overall_ei, chosen index.
   chooser_next.npz the reference's GPEIOptChooser.next / GPEIperSecChooser.next on Branin
                    (seeded; burnin + MCMC + refinement), the point they propose.
+  chooser_next_pending.npz  the same with three pending jobs (fantasy branch).
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
 """
 import os
@@ -232,6 +233,45 @@ def gen_chooser_next(mods, tmp):
                         durations=durations, candidates=cand, pending=pend, complete=comp, **out)
 
 
+def gen_chooser_next_pending(mods, tmp):
+    """The reference's GPEIChooser.next and GPEIOptChooser.next with PENDING experiments
+    (fantasy branch), seeded, on Branin."""
+    grid, values, durations, cand, pend, comp = _branin_inputs(mods, 12, 300)
+    pend = cand[:3].copy(); cand = cand[3:].copy()       # three jobs still running
+    out = {}
+    for seed in range(700, 740):
+        ch = mods["GPEIChooser"].GPEIChooser(tempfile.mkdtemp(prefix="spx_golden_pg_"), mcmc_iters=3,
+                                             pending_samples=9)
+        eis = []
+        orig = ch.compute_ei
+        ch.compute_ei = lambda c, p, x, v, orig=orig, eis=eis: (eis.append(orig(c, p, x, v)) or eis[-1])
+        npr.seed(seed)
+        try:
+            job = ch.next(grid, values, durations, cand, pend, comp)
+        except Exception as e:
+            print("pending gpei seed", seed, "reference raised:", e)
+            ch.ls = np.ones(2); ch.amp2 = ch.noise = ch.mean = 0.0
+            continue
+        out.update(g_seed=seed, g_job=int(job), g_ei=np.array(eis).T)
+        break
+    for seed in range(800, 840):
+        ch = mods["GPEIOptChooser"].GPEIOptChooser(tempfile.mkdtemp(prefix="spx_golden_po_"), mcmc_iters=3,
+                                                   burnin=4, grid_subset=3, pending_samples=8,
+                                                   use_multiprocessing=0)
+        npr.seed(seed)
+        try:
+            job = ch.next(grid, values, durations, cand, pend, comp)
+        except Exception as e:
+            print("pending opt seed", seed, "reference raised:", e)
+            continue
+        out.update(o_seed=seed, o_is_new=int(isinstance(job, tuple)),
+                   o_index=int(job[0] if isinstance(job, tuple) else job),
+                   o_point=np.asarray(job[1] if isinstance(job, tuple) else grid[job]))
+        break
+    np.savez_compressed(os.path.join(OUT, "chooser_next_pending.npz"), grid=grid, values=values,
+                        durations=durations, candidates=cand, pending=pend, complete=comp, **out)
+
+
 def gen_slice(mods, tmp):
     util = mods["util"]
     comp, cand, vals, hypers = synthetic_problem(30, 10, 3, 1, 41)
@@ -262,7 +302,7 @@ def gen_slice(mods, tmp):
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_slice):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 

@@ -6,6 +6,7 @@ evaluated by libspx.so on the GPU (see _base.py)."""
 from __future__ import absolute_import, print_function
 
 import numpy as np
+import numpy.random as npr
 
 from .. import util
 from ..helpers import log
@@ -45,11 +46,15 @@ class GPEIChooser(GPEIBase):
         # The reference alternates "sample hypers" and "compute_ei" (:145-151).
         # Without pending experiments compute_ei consumes no random numbers, so
         # drawing all H samples first and scoring them in one GPU call is the
-        # same computation.
-        rows = []
+        # same computation; with pending ones its fantasy normals are drawn here,
+        # right after the sample they belong to.
+        rows, randn = [], []
         for _ in range(self.mcmc_iters):
             self.sample_hypers(comp, vals)
             self._log_hypers()
             rows.append(self.current_hyper_row())
-        best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand, vals, np.array(rows))
+            if pend.shape[0] > 0:
+                # compute_ei's only use of the RNG (:238), at the same point of the stream
+                randn.append(npr.randn(pend.shape[0], self.pending_samples))
+        best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand, vals, np.array(rows), randn=randn)
         return int(candidates[best])

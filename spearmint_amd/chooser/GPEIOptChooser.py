@@ -104,8 +104,25 @@ class GPEIOptChooser(GPEIBase):
                          for h in self.hyper_samples])
 
     # -- local refinement on the host (:360-388 summed over draws) ---------------
-    def _refine(self, points, comp, vals):
-        models = [hostgp.PointModel(comp, vals, h) for h in self.hyper_samples]
+    def _fantasy_normals(self, pend):
+        """The reference restores the RNG state captured in _real_init before every
+        fantasy draw (:588), so all draws share one (P, S) matrix -- and the global
+        stream is left right after it."""
+        out = []
+        for _ in self.hyper_samples:
+            npr.set_state(self.randomstate)
+            out.append(npr.randn(pend.shape[0], self.pending_samples))
+        return out
+
+    def _refine(self, points, comp, vals, pend):
+        if pend.shape[0] > 0:
+            models = []
+            for h in self.hyper_samples:
+                npr.set_state(self.randomstate)
+                models.append(hostgp.PendingPointModel(comp, pend, vals, h,
+                                                       npr.randn(pend.shape[0], self.pending_samples)))
+        else:
+            models = [hostgp.PointModel(comp, vals, h) for h in self.hyper_samples]
 
         def objective(x):
             total, grad = 0.0, np.zeros(x.shape[0])
@@ -152,13 +169,15 @@ class GPEIOptChooser(GPEIBase):
         rows = self.hyper_rows()
 
         # pass 1 over grid + sprayed points, keep the grid_subset best (:269-271)
-        _, mean1, _ = self.ei_over_hypers_gpu(comp, pend, cand2, vals, rows, want_draws=False)
+        randn = self._fantasy_normals(pend) if pend.shape[0] > 0 else None
+        _, mean1, _ = self.ei_over_hypers_gpu(comp, pend, cand2, vals, rows, want_draws=False, randn=randn)
         keep = np.argsort(mean1)[-self.grid_subset:]
-        refined = self._refine(cand2[keep, :], comp, vals)
+        refined = self._refine(cand2[keep, :], comp, vals, pend)
 
         # pass 2 over grid + refined points (:292-299)
         cand_all = np.vstack((cand, refined))
-        best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand_all, vals, rows)
+        randn = self._fantasy_normals(pend) if pend.shape[0] > 0 else None
+        best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand_all, vals, rows, randn=randn)
         if best >= numcand:
             return (int(numcand), cand_all[best, :])
         return int(candidates[best])

@@ -192,19 +192,49 @@ class GPEIBase(object):
             % (prefix, self.mean, np.sqrt(self.amp2), self.noise, np.min(self.ls), np.max(self.ls)))
 
     # -- the hot path: one call into libspx ---------------------------------------
-    def ei_over_hypers_gpu(self, comp, pend, cand, vals, hyper_rows, want_draws=True):
+    def ei_over_hypers_gpu(self, comp, pend, cand, vals, hyper_rows, want_draws=True, randn=None):
         """overall_ei[M, H] and the index of argmax(mean) -- the replacement of
         the reference's compute_ei loop (GPEIChooser.py:143-153,
         GPEIOptChooser.py:331-341).  Raises numpy.linalg.LinAlgError when a
         covariance is not positive definite, exactly where spla.cholesky would."""
         if pend.shape[0] > 0:
-            raise NotImplementedError(
-                "pending-experiment fantasies (GPEIChooser.py:209-266) are not on the GPU path yet; "
-                "run with --max-concurrent=1 / no 'P' lines")
+            return self._ei_with_pending_gpu(comp, pend, cand, vals, hyper_rows, randn, want_draws)
         hyper_rows = np.ascontiguousarray(np.atleast_2d(hyper_rows), dtype=np.float64)
         self._lp_key = None     # the one-shot call below replaces the engine's resident observations
         idx, val, mean, draws = self.engine().ei_grid(comp, vals, cand, hyper_rows,
                                                       want_mean=True, want_draws=want_draws)
+        self.last_overall_ei = draws
+        self.last_ei_mean = mean
+        return idx, mean, draws
+
+    def _ei_with_pending_gpu(self, comp, pend, cand, vals, hyper_rows, randn, want_draws):
+        """Pending experiments: fantasise their outcomes (GPEIChooser.py:209-266).
+        GPU: factorisation of cov([comp; pend]) for every draw, K(X*,X), the solve,
+        Sigma beta^2 and the S fantasy means, EI averaged over fantasies.  Host: the
+        O(N^2 P) posterior of the P pending points and the S joint fantasy draws
+        (`randn[h]` is the (P, S) standard-normal matrix of draw h, drawn by the
+        caller at the point where the reference consumes the RNG)."""
+        hyper_rows = np.ascontiguousarray(np.atleast_2d(hyper_rows), dtype=np.float64)
+        H, n_comp, n_pend = hyper_rows.shape[0], comp.shape[0], pend.shape[0]
+        eng = self.engine()
+        self._lp_key = None
+        comp_pend = np.concatenate((comp, pend))
+        eng.set_observations(comp_pend, np.concatenate((vals, np.zeros(n_pend))))
+        eng.set_candidates(cand)
+        eng.set_hypers(hyper_rows)
+        eng.factor()
+        S = randn[0].shape[1]
+        fant = np.empty((H, n_comp + n_pend, S))
+        bests = np.empty((H, S))
+        for h in range(H):
+            chol = eng.get_factor(h, want_K=False, want_alpha=False)[1]
+            fant[h], bests[h] = hostgp.fantasize_pending(comp, pend, vals, hyper_rows[h],
+                                                         chol[:n_comp, :n_comp], randn[h])
+        eng.set_fantasies(fant, bests)
+        eng.ei_run()
+        idx, _ = eng.best()
+        mean = eng.ei_mean()
+        draws = eng.ei_draws() if want_draws else None
         self.last_overall_ei = draws
         self.last_ei_mean = mean
         return idx, mean, draws

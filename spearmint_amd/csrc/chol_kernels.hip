@@ -284,17 +284,18 @@ void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT
 // ---------------------------------------------------------------------------
 // gamma = W (vals - mean)   (one thread per row i, coalesced over i)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gamma(const double* __restrict__ WT,
-                                               const double* __restrict__ vals /*[nh][Np] or [Np]*/,
-                                               int vals_stride, const double* __restrict__ htab,
+__global__ __launch_bounds__(256) void k_gamma(const double* __restrict__ WT, size_t wt_stride,
+                                               const double* __restrict__ vals, size_t vals_stride,
+                                               const double* __restrict__ htab, int htab_stride,
                                                double* __restrict__ gamma, int N, int Np)
 {
+    // batch entry b = blockIdx.y: its own right-hand side, and (strides permitting) its own W / mean
     __shared__ double r[256];
-    const int h = blockIdx.y;
+    const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const double* Wh = WT + (size_t)h * Np * Np;
-    const double mean = htab[h * SPX_HT + 0];
-    const double* vh = vals + (size_t)h * vals_stride;
+    const double* Wh = WT + (size_t)b * wt_stride;
+    const double mean = htab[b * htab_stride + 0];
+    const double* vh = vals + (size_t)b * vals_stride;
     double acc = 0.0;
     const int jmax = blockIdx.x * 256 + 255;  // rows this block needs: j <= i
     for (int jb = 0; jb <= jmax; jb += 256) {
@@ -305,14 +306,23 @@ __global__ __launch_bounds__(256) void k_gamma(const double* __restrict__ WT,
         const int jn = (i < Np) ? min(256, i - jb + 1) : 0;
         for (int t = 0; t < jn; ++t) acc += Wh[(size_t)(jb + t) * Np + i] * r[t];
     }
-    if (i < Np) gamma[(size_t)h * Np + i] = acc;
+    if (i < Np) gamma[(size_t)b * Np + i] = acc;
 }
 
 void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
                   double* gamma, int N, int Np, int nh)
 {
-    hipLaunchKernelGGL(k_gamma, dim3(Np / 256 + (Np % 256 != 0), nh), dim3(256), 0, s, WT, vals, 0,
-                       htab, gamma, N, Np);
+    // one right-hand side (vals) shared by nh draws, each with its own W and mean
+    hipLaunchKernelGGL(k_gamma, dim3(Np / 256 + (Np % 256 != 0), nh), dim3(256), 0, s, WT,
+                       (size_t)Np * Np, vals, (size_t)0, htab, SPX_HT, gamma, N, Np);
+}
+
+// S right-hand sides (fantasy columns, [S][n] contiguous) against ONE draw's W and mean
+void launch_gamma_multi(hipStream_t s, const double* WT_h, const double* rhs, const double* htab_h,
+                        double* gamma, int N, int Np, int S)
+{
+    hipLaunchKernelGGL(k_gamma, dim3(Np / 256 + (Np % 256 != 0), S), dim3(256), 0, s, WT_h,
+                       (size_t)0, rhs, (size_t)N, htab_h, 0, gamma, N, Np);
 }
 
 // alpha = W^T gamma  == K^-1 (vals - mean);  one wavefront per row j of WT

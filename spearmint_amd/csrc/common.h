@@ -44,6 +44,8 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh);
 void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
                   double* gamma, int N, int Np, int nh);
+void launch_gamma_multi(hipStream_t s, const double* WT_h, const double* rhs, const double* htab_h,
+                        double* gamma, int N, int Np, int S);
 void launch_alpha(hipStream_t s, const double* WT, const double* gamma, double* alpha, int Np, int nh);
 void launch_fwd_solve(hipStream_t s, const double* L, const double* Dinv, const double* vals,
                       const double* htab, double* gamma, int N, int Np, int nh);
@@ -52,7 +54,12 @@ void launch_logprob(hipStream_t s, const double* L, const double* gamma, const i
 
 // predict_kernels.hip
 void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
-                         double* part_ss, double* part_bg, int Np, int Mc, int nh);
+                         double* part_ss, double* part_bg, int Np, int Mc, int nh,
+                         const double* gammaS = nullptr, int S = 0, double* part_bgS = nullptr);
+void launch_ei_finalize_fant(hipStream_t s, const double* part_ss, const double* part_bgS,
+                             const double* htab, const double* bests, const double* time_m,
+                             double* ei_draw, int nrb, int Mc, int nh, int S, int64_t c0, int64_t M,
+                             int64_t Mp, int h0);
 void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part_bg,
                         const double* htab, const double* time_m, double best, double* ei_draw,
                         double* mom_m, double* mom_v, int nrb, int Mc, int nh, int64_t c0,

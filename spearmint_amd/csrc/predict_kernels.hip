@@ -31,7 +31,9 @@
 __global__ __launch_bounds__(256, 2) void k_predict_gemm(
     const double* __restrict__ WT, const double* __restrict__ Kst,
     const double* __restrict__ gamma, double* __restrict__ part_ss,
-    double* __restrict__ part_bg, int Np, int Mc, int nh, int ncb, int nrb)
+    double* __restrict__ part_bg, int Np, int Mc, int nh, int ncb, int nrb,
+    const double* __restrict__ gammaS /*[nh][S][Np] or null*/, int S,
+    double* __restrict__ part_bgS /*[nrb][2][nh][S][Mc]*/)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;                      // [2][BK][LDT]
@@ -168,10 +170,39 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(
         part_ss[o] = ss;
         part_bg[o] = bg;
     }
+
+    // Pending-experiment fantasies (GPEIChooser.py:253-258): the predictive mean is needed
+    // against S right-hand sides, func_m[c][s] = sum_i beta[i][c] Gamma_s[i] + mean.  Each wave
+    // reduces its 64 rows; the two row halves (wm) are written separately and summed, in
+    // fixed order, by k_ei_finalize_fant.
+    if (S > 0) {
+        const double* gS = gammaS + (size_t)h * S * Np + (size_t)ib * BM + 64 * wm;
+        double* outS = part_bgS + ((((size_t)ib * 2 + wm) * nh + h) * S) * Mc + (size_t)cb * BN + 64 * wn;
+        for (int sidx = 0; sidx < S; ++sidx) {
+            const double* gs = gS + (size_t)sidx * Np;
+            double gv[4][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[mt][r] = gs[16 * mt + g + 4 * r];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                double bg = 0.0;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bg = fma(acc[mt][nt][r], gv[mt][r], bg);
+                bg += __shfl_xor(bg, 16);
+                bg += __shfl_xor(bg, 32);
+                if (g == 0) outS[(size_t)sidx * Mc + 16 * nt + li] = bg;
+            }
+        }
+    }
 }
 
 void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
-                         double* part_ss, double* part_bg, int Np, int Mc, int nh)
+                         double* part_ss, double* part_bg, int Np, int Mc, int nh,
+                         const double* gammaS, int S, double* part_bgS)
 {
     const int ncb = Mc / BN, nrb = Np / BM;
     const size_t lds = (size_t)(4 * BK * LDT) * sizeof(double);
@@ -183,7 +214,7 @@ void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, con
     }
     const int grid = 8 * ((ncb + 7) / 8) * nrb * nh;
     hipLaunchKernelGGL(k_predict_gemm, dim3(grid), dim3(256), lds, s, WT, Kst, gamma,
-                       part_ss, part_bg, Np, Mc, nh, ncb, nrb);
+                       part_ss, part_bg, Np, Mc, nh, ncb, nrb, gammaS, S, part_bgS);
 }
 
 // ---------------------------------------------------------------------------
@@ -250,6 +281,61 @@ void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part
 {
     hipLaunchKernelGGL(k_ei_finalize, dim3((Mc + 255) / 256, nh), dim3(256), 0, s, part_ss, part_bg,
                        htab, time_m, best, ei_draw, mom_m, mom_v, nrb, Mc, nh, c0, M, Mp, h0);
+}
+
+// EI against S fantasies, averaged over S in numpy's pairwise order
+// (np.mean(ei, axis=1) on the (M, S) array of GPEIChooser.py:261-266; S <= 128).
+__global__ __launch_bounds__(256) void k_ei_finalize_fant(
+    const double* __restrict__ part_ss, const double* __restrict__ part_bgS,
+    const double* __restrict__ htab, const double* __restrict__ bests /*[nh][S]*/,
+    const double* __restrict__ time_m, double* __restrict__ ei_draw, int nrb, int Mc, int nh,
+    int S, int64_t c0, int64_t M, int64_t Mp, int h0)
+{
+#pragma clang fp contract(off)
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    if (c >= Mc || c0 + c >= M) return;
+    double ss = 0.0;
+    for (int ib = 0; ib < nrb; ++ib) ss += part_ss[((size_t)ib * nh + h) * Mc + c];
+    const double mean = htab[h * SPX_HT + 0];
+    const double func_v = htab[h * SPX_HT + 3] - ss;
+    const double* bh = bests + (size_t)h * S;
+    double r8[8];
+    double res = -0.0;
+    const int nfull = (S < 8) ? 0 : S - (S % 8);
+    for (int sidx = 0; sidx < S; ++sidx) {
+        double bg = 0.0;
+        for (int ib = 0; ib < nrb; ++ib) {
+            const size_t o0 = ((((size_t)ib * 2 + 0) * nh + h) * S + sidx) * Mc + c;
+            const size_t o1 = ((((size_t)ib * 2 + 1) * nh + h) * S + sidx) * Mc + c;
+            bg += part_bgS[o0] + part_bgS[o1];
+        }
+        const double ei = ei_dev(bg + mean, func_v, bh[sidx]);
+        // numpy pairwise_sum for n <= 128, streamed
+        if (S < 8) {
+            res += ei;
+        } else if (sidx < 8) {
+            r8[sidx] = ei;
+        } else if (sidx < nfull) {
+            r8[sidx & 7] += ei;
+        } else {
+            if (sidx == nfull) res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+            res += ei;
+        }
+    }
+    if (S >= 8 && nfull == S) res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+    double out = (0.0 + res) / (double)S;
+    if (time_m) out = out / time_m[(size_t)h * Mc + c];
+    ei_draw[(size_t)(h0 + h) * Mp + c0 + c] = out;
+}
+
+void launch_ei_finalize_fant(hipStream_t s, const double* part_ss, const double* part_bgS,
+                             const double* htab, const double* bests, const double* time_m,
+                             double* ei_draw, int nrb, int Mc, int nh, int S, int64_t c0, int64_t M,
+                             int64_t Mp, int h0)
+{
+    hipLaunchKernelGGL(k_ei_finalize_fant, dim3((Mc + 255) / 256, nh), dim3(256), 0, s, part_ss,
+                       part_bgS, htab, bests, time_m, ei_draw, nrb, Mc, nh, S, c0, M, Mp, h0);
 }
 
 // ---------------------------------------------------------------------------

@@ -86,6 +86,9 @@ struct spx_handle {
     DevBuf Xs, X2s, s1, Lm, WT, Dinv, gamma, alpha, info, lp;
     DevBuf Cs[2], s2[2], Kst[2], part_ss[2], part_bg[2], time_m[2], ei_draw, ei_mean, mom_m, mom_v;
     DevBuf am_val, am_idx, am_out_val, am_out_idx, scratch;
+    // pending-experiment fantasies (spx_set_fantasies): S right-hand sides per draw
+    int S = 0;
+    DevBuf fantT, gammaS, bests, part_bgS[2];
 
     double best_val = 0.0;
     int64_t best_idx = -1;
@@ -188,6 +191,7 @@ void spx_destroy(spx_handle* h)
                           &h->s1, &h->Lm, &h->WT, &h->Dinv, &h->gamma, &h->alpha, &h->info, &h->lp,
                           &h->Cs[0], &h->s2[0], &h->Kst[0], &h->part_ss[0], &h->part_bg[0], &h->time_m[0],
                           &h->Cs[1], &h->s2[1], &h->Kst[1], &h->part_ss[1], &h->part_bg[1], &h->time_m[1],
+                          &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->am_val, &h->am_idx,
                           &h->am_out_val, &h->am_out_idx, &h->scratch};
         for (DevBuf* b : bufs) b->release();
@@ -239,7 +243,7 @@ int spx_set_observations(spx_handle* h, const double* comp, const double* vals, 
     }
     h->best = b;
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->have_obs = true; h->have_time = false; h->factored = false; h->ran = false;
+    h->have_obs = true; h->have_time = false; h->factored = false; h->ran = false; h->S = 0;
     return SPX_OK;
 }
 
@@ -266,7 +270,7 @@ int spx_set_hypers(spx_handle* h, const double* hypers, int32_t H)
     if (!h->have_obs) return fail(SPX_ERR_ARG, "spx_set_hypers: call spx_set_observations first");
     h->H = H;
     h->hyp_host.assign(hypers, hypers + (size_t)H * (3 + h->D));
-    h->have_hyp = true; h->have_time = false; h->factored = false; h->ran = false;
+    h->have_hyp = true; h->have_time = false; h->factored = false; h->ran = false; h->S = 0;
     return SPX_OK;
 }
 
@@ -375,6 +379,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
         if (info[i]) { h->not_pd_draw = i; h->not_pd_pivot = info[i] - 1; break; }
     h->factored = !lean;
     h->ran = false;
+    h->S = 0;
     if (h->not_pd_draw >= 0 && !tolerate_not_pd) {
         h->factored = false;
         return fail(SPX_ERR_NOT_PD, "%d-th leading minor of the array is not positive definite (draw %d%s)",
@@ -394,6 +399,38 @@ int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot)
     if (!h) return fail(SPX_ERR_ARG, "null handle");
     if (draw) *draw = h->not_pd_draw;
     if (pivot) *pivot = h->not_pd_pivot;
+    return SPX_OK;
+}
+
+int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, int32_t S)
+{
+    if (!h) return fail(SPX_ERR_ARG, "spx_set_fantasies: null handle");
+    if (!fant || !bests || S <= 0) { h->S = 0; return SPX_OK; }   // clear
+    if (!h->factored) return fail(SPX_ERR_ARG, "spx_set_fantasies: call spx_factor first");
+    if (S > 128) return fail(SPX_ERR_ARG, "spx_set_fantasies: at most 128 fantasies (got %d)", S);
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int H = h->H, Np = h->Np;
+    const int64_t n = h->N;
+    // host transpose to [H][S][n] so that every fantasy column is a contiguous right-hand side
+    std::vector<double> ft((size_t)H * S * n);
+    for (int d = 0; d < H; ++d)
+        for (int64_t i = 0; i < n; ++i)
+            for (int c = 0; c < S; ++c)
+                ft[((size_t)d * S + c) * n + i] = fant[((size_t)d * n + i) * S + c];
+    if ((rc = h->fantT.reserve(ft.size() * 8))) return rc;
+    if ((rc = h->gammaS.reserve((size_t)H * S * Np * 8))) return rc;
+    if ((rc = h->bests.reserve((size_t)H * S * 8))) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->fantT.p, ft.data(), ft.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->bests.p, bests, (size_t)H * S * 8, hipMemcpyHostToDevice, s));
+    for (int d = 0; d < H; ++d)   // Gamma_d = W_d (F_d - mean_d), one launch per draw, S columns each
+        launch_gamma_multi(s, h->WT.d() + (size_t)d * Np * Np, h->fantT.d() + (size_t)d * S * n,
+                           h->htab.d() + (size_t)d * SPX_HT, h->gammaS.d() + (size_t)d * S * Np, (int)n, Np, S);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    h->S = S;
+    h->ran = false;
     return SPX_OK;
 }
 
@@ -431,6 +468,17 @@ int spx_ei_run(spx_handle* h, int32_t flags)
     const int nrb = Np / SPX_BM;
     int64_t Mc; int Hb;
     plan_chunks(h, &Mc, &Hb);
+    const int S = h->S;
+    if (S > 0) {
+        // the per-fantasy partial means are [nrb][2][S][Mc]: keep them under 256 MB
+        Hb = 1;
+        int64_t cap = (256ll << 20) / ((int64_t)nrb * 2 * S * 8) / SPX_BN * SPX_BN;
+        if (cap < SPX_BN) cap = SPX_BN;
+        if (Mc > cap) {
+            const int64_t nchunks = (Mp + cap - 1) / cap;
+            Mc = round_up((Mp + nchunks - 1) / nchunks, SPX_BN);
+        }
+    }
 
     const int ns = h->nstreams;
     for (int b = 0; b < 2; ++b) {
@@ -443,6 +491,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
             if ((rc = h->Kst[b].reserve((size_t)Hb * Np * Mc * 8))) return rc;
             if ((rc = h->part_ss[b].reserve((size_t)nrb * Hb * Mc * 8))) return rc;
             if ((rc = h->part_bg[b].reserve((size_t)nrb * Hb * Mc * 8))) return rc;
+            if (S > 0 && (rc = h->part_bgS[b].reserve((size_t)nrb * 2 * S * Mc * 8))) return rc;
         }
     }
     if ((rc = h->ei_draw.reserve((size_t)H * Mp * 8))) return rc;
@@ -501,12 +550,21 @@ int spx_ei_run(spx_handle* h, int32_t flags)
                                                        h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb));
             TIMED_S(ST_PREDICT_GEMM, sk, launch_predict_gemm(sk, h->WT.d() + (size_t)h0 * nn, h->Kst[k].d(),
                                                              h->gamma.d() + (size_t)h0 * Np, h->part_ss[k].d(),
-                                                             h->part_bg[k].d(), Np, mc, nhb));
-            TIMED_S(ST_EI_FINALIZE, sk, launch_ei_finalize(sk, h->part_ss[k].d(), h->part_bg[k].d(),
-                                                           h->htab.d() + (size_t)h0 * SPX_HT,
-                                                           per_sec ? tm + (size_t)h0 * mc : nullptr, h->best,
-                                                           h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
-                                                           keep_mom ? h->mom_v.d() : nullptr, nrb, mc, nhb, c0, M, Mp, h0));
+                                                             h->part_bg[k].d(), Np, mc, nhb,
+                                                             S > 0 ? h->gammaS.d() + (size_t)h0 * S * Np : nullptr, S,
+                                                             S > 0 ? h->part_bgS[k].d() : nullptr));
+            if (S > 0)
+                TIMED_S(ST_EI_FINALIZE, sk, launch_ei_finalize_fant(sk, h->part_ss[k].d(), h->part_bgS[k].d(),
+                                                                    h->htab.d() + (size_t)h0 * SPX_HT,
+                                                                    h->bests.d() + (size_t)h0 * S,
+                                                                    per_sec ? tm + (size_t)h0 * mc : nullptr,
+                                                                    h->ei_draw.d(), nrb, mc, nhb, S, c0, M, Mp, h0));
+            else
+                TIMED_S(ST_EI_FINALIZE, sk, launch_ei_finalize(sk, h->part_ss[k].d(), h->part_bg[k].d(),
+                                                               h->htab.d() + (size_t)h0 * SPX_HT,
+                                                               per_sec ? tm + (size_t)h0 * mc : nullptr, h->best,
+                                                               h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
+                                                               keep_mom ? h->mom_v.d() : nullptr, nrb, mc, nhb, c0, M, Mp, h0));
         }
         if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[2 + par], h->stream2));
     }
@@ -533,7 +591,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
         h->st_ms[ST_EI_RUN_TOTAL] += ms; h->st_n[ST_EI_RUN_TOTAL] += 1;
     }
     h->ran = true;
-    h->ran_moments = keep_mom;
+    h->ran_moments = keep_mom && S == 0;
     return SPX_OK;
 }
 

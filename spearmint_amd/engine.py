@@ -43,6 +43,7 @@ ABI = {
     "spx_set_hypers": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int32]),
     "spx_set_time_model": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
     "spx_factor": (ctypes.c_int, [_vp]),
+    "spx_set_fantasies": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, ctypes.c_int32]),
     "spx_ei_run": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "spx_get_best": (ctypes.c_int, [_vp, _c_int64_p, _c_double_p]),
     "spx_get_ei_mean": (ctypes.c_int, [_vp, _c_double_p]),
@@ -189,6 +190,17 @@ class Engine(object):
     # -- hot path ---------------------------------------------------------
     def factor(self):
         self._check(self._lib.spx_factor(self._h))
+
+    def set_fantasies(self, fant, bests):
+        """fant (H, n, S) fantasy value columns per draw, bests (H, S) -- see include/spx.h."""
+        if fant is None:
+            self._check(self._lib.spx_set_fantasies(self._h, None, None, 0))
+            return
+        fant = _f64(fant)
+        bests = _f64(bests)
+        if fant.ndim != 3 or fant.shape[0] != self.H or fant.shape[1] != self.N or bests.shape != (self.H, fant.shape[2]):
+            raise ValueError("fant must be (H, n, S) and bests (H, S)")
+        self._check(self._lib.spx_set_fantasies(self._h, _dp(fant), _dp(bests), fant.shape[2]))
 
     def ei_run(self, flags=0):
         self._check(self._lib.spx_ei_run(self._h, int(flags)))

@@ -132,3 +132,59 @@ class PerSecPointModel(PointModel):
         g_t = 0.5 * self.t_amp2 * np.dot(self.t_alpha.T, dkt) * time_m
         g = (time_m * g - ei * g_t) / (time_m ** 2)
         return -np.sum(ei / time_m), g.flatten()
+
+
+def fantasize_pending(comp, pend, vals, hyper_row, obsv_chol, randn_ps):
+    """Host part of the pending branch (GPEIChooser.py:219-249), O(N^2 P):
+    posterior of the P pending points given the N completed ones, S joint
+    fantasy outcomes.  `obsv_chol` is the N x N leading block of the Cholesky
+    factor of cov([comp; pend]) -- the reference's "sub-Cholesky" (:226) --
+    which the caller fetches from the GPU factorisation.
+    Returns fant_vals ((N+P) x S) and bests (S,)."""
+    mean, noise, amp2 = hyper_row[0], hyper_row[1], hyper_row[2]
+    ls = np.asarray(hyper_row[3:], dtype=float)
+    p = pend.shape[0]
+    pend_cross = amp2 * matern52(ls, comp, pend)
+    pend_kappa = amp2 * (matern52(ls, pend) + 1e-6 * np.eye(p))
+    alpha = spla.cho_solve((obsv_chol, True), vals - mean)
+    beta = spla.cho_solve((obsv_chol, True), pend_cross)
+    pend_m = np.dot(pend_cross.T, alpha) + mean
+    pend_k = pend_kappa - np.dot(pend_cross.T, beta)
+    pend_chol = spla.cholesky(pend_k, lower=True)
+    pend_fant = np.dot(pend_chol, randn_ps) + pend_m[:, None]
+    s = randn_ps.shape[1]
+    fant_vals = np.concatenate((np.tile(vals[:, np.newaxis], (1, s)), pend_fant))
+    return fant_vals, np.min(fant_vals, axis=0)
+
+
+class PendingPointModel(object):
+    """EI (averaged over fantasies) and its gradient at a few points, with
+    pending experiments -- the host-side refinement of GPEIOptChooser.py:441-525."""
+
+    def __init__(self, comp, pend, vals, hyper, randn_ps):
+        self.mean, self.noise, self.amp2 = float(hyper[0]), float(hyper[1]), float(hyper[2])
+        self.ls = np.asarray(hyper[3], dtype=float)
+        self.comp_pend = np.concatenate((comp, pend))
+        n = comp.shape[0]
+        self.chol = spla.cholesky(obs_cov(self.amp2, self.noise, self.ls, self.comp_pend), lower=True)
+        row = np.concatenate(([self.mean, self.noise, self.amp2], self.ls))
+        fant_vals, self.bests = fantasize_pending(comp, pend, vals, row, self.chol[:n, :n], randn_ps)
+        self.alpha = spla.cho_solve((self.chol, True), fant_vals - self.mean)
+
+    def neg_ei_and_grad(self, x):
+        d = self.comp_pend.shape[1]
+        x = np.reshape(x, (-1, d))
+        kx = self.amp2 * matern52(self.ls, self.comp_pend, x)
+        beta = spla.solve_triangular(self.chol, kx, lower=True)
+        m = np.dot(kx.T, self.alpha) + self.mean
+        v = self.amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
+        s = np.sqrt(v[:, np.newaxis])
+        u = (self.bests[np.newaxis, :] - m) / s
+        cdf = sps.norm.cdf(u)
+        pdf = sps.norm.pdf(u)
+        ei = s * (u * cdf + pdf)
+        dk = np.squeeze(matern52_grad_wrt_first(self.ls, self.comp_pend, x), axis=1)
+        d_m = np.dot(self.alpha.T, dk)
+        d_v = np.dot(-2 * spla.cho_solve((self.chol, True), kx).T, dk)
+        g = 0.5 * self.amp2 * (d_m * np.tile(-cdf, (d, 1)).T + (d_v.T * (0.5 * pdf / s)).T)
+        return float(-np.mean(ei, axis=1)[0]), np.mean(g, axis=0).flatten()

@@ -10,6 +10,47 @@ from oracle import gp_ei_oracle as orc
 class OracleEngine(object):
     def __init__(self):
         self.calls = []
+        self.fant = None
+
+    # -- resident-data mode (what the pending path of the choosers uses) ------------
+    def set_observations(self, comp, vals):
+        self.comp, self.vals, self.fant = np.asarray(comp, float), np.asarray(vals, float), None
+
+    def set_candidates(self, cand, index_base=0):
+        self.cand = np.asarray(cand, float)
+
+    def set_hypers(self, hypers):
+        self.hypers, self.fant = np.atleast_2d(hypers), None
+
+    def factor(self):
+        self.chols = [orc.posterior(self.comp, self.vals, h)[1] for h in self.hypers]
+
+    def get_factor(self, draw, want_K=True, want_L=True, want_alpha=True):
+        return None, self.chols[draw], None
+
+    def set_fantasies(self, fant, bests):
+        self.fant, self.bests = np.asarray(fant, float), np.asarray(bests, float)
+
+    def ei_run(self, flags=0):
+        H = self.hypers.shape[0]
+        if self.fant is None:
+            ei = orc.ei_over_hypers(self.comp, self.cand, self.vals, self.hypers)
+        else:
+            ei = np.stack([orc.compute_ei_fantasies(self.comp, self.cand, self.hypers[h], self.fant[h], self.bests[h])
+                           for h in range(H)], axis=1)
+        self._ei = ei
+        self.calls.append(("ei_run", self.cand.shape[0], H, None if self.fant is None else self.fant.shape[2]))
+
+    def best(self):
+        m = np.mean(self._ei, axis=1)
+        i = int(np.argmax(m))
+        return i, float(m[i])
+
+    def ei_mean(self):
+        return np.mean(self._ei, axis=1)
+
+    def ei_draws(self):
+        return self._ei
 
     def ei_grid(self, comp, vals, cand, hypers, want_mean=True, want_draws=False, flags=0):
         ei = orc.ei_over_hypers(comp, cand, vals, hypers)

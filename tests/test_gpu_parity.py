@@ -340,3 +340,68 @@ def test_gpu_loglikelihood_large_n_and_not_pd(eng):
     eng.set_candidates(cand)
     with pytest.raises(ValueError):
         eng.ei_run()
+
+
+# ---- pending experiments ("next" row 2): fantasies on the GPU --------------------------
+def test_golden_pending_fantasies(eng, golden_dir):
+    from spearmint_amd import hostgp
+    g = _g(golden_dir, "ei_pending.npz")
+    comp, pend, cand, vals, hypers = g["comp"], g["pend"], g["cand"], g["vals"], g["hypers"]
+    H, N, P, S = hypers.shape[0], len(comp), len(pend), g["randn"].shape[2]
+    comp_pend = np.concatenate((comp, pend))
+    eng.set_observations(comp_pend, np.concatenate((vals, np.zeros(P))))
+    eng.set_candidates(cand); eng.set_hypers(hypers); eng.factor()
+    fant = np.empty((H, N + P, S)); bests = np.empty((H, S))
+    for h in range(H):
+        chol = eng.get_factor(h, want_K=False, want_alpha=False)[1]
+        fant[h], bests[h] = hostgp.fantasize_pending(comp, pend, vals, hypers[h], chol[:N, :N], g["randn"][h])
+    eng.set_fantasies(fant, bests)
+    eng.ei_run()
+    draws = eng.ei_draws()
+    assert_ei_close(draws, g["ei"], rtol=1e-6)
+    assert eng.best()[0] == int(np.argmax(np.mean(g["ei"], axis=1)))
+    # clearing the fantasies gives back the plain path on the same resident data
+    eng.set_fantasies(None, None)
+    eng.ei_run()
+    plain = orc.ei_over_hypers(comp_pend, cand, np.concatenate((vals, np.zeros(P))), hypers)
+    assert_ei_close(eng.ei_draws(), plain, rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,P,M,D,H,S,seed", [(130, 5, 700, 4, 3, 100, 41), (300, 2, 1500, 9, 2, 8, 42),
+                                              (64, 1, 300, 2, 2, 7, 43), (500, 7, 900, 6, 2, 128, 44)])
+def test_fantasies_against_oracle(eng, N, P, M, D, H, S, seed):
+    from spearmint_amd import hostgp
+    comp, cand, vals, hypers = synthetic_problem(N, M, D, H, seed)
+    rs = np.random.RandomState(seed)
+    pend = rs.rand(P, D)
+    comp_pend = np.concatenate((comp, pend))
+    eng.set_observations(comp_pend, np.concatenate((vals, np.zeros(P))))
+    eng.set_candidates(cand); eng.set_hypers(hypers); eng.factor()
+    fant = np.empty((H, N + P, S)); bests = np.empty((H, S)); ref = np.empty((M, H))
+    for h in range(H):
+        chol = eng.get_factor(h, want_K=False, want_alpha=False)[1]
+        fant[h], bests[h] = hostgp.fantasize_pending(comp, pend, vals, hypers[h], chol[:N, :N], rs.randn(P, S))
+        ref[:, h] = orc.compute_ei_fantasies(comp_pend, cand, hypers[h], fant[h], bests[h])
+    eng.set_fantasies(fant, bests)
+    eng.ei_run()
+    assert_ei_close(eng.ei_draws(), ref, rtol=1e-6)
+    assert eng.best()[0] == orc.choose(ref)
+    assert np.array_equal(eng.ei_mean(), np.mean(eng.ei_draws(), axis=1))
+
+
+def test_choosers_with_pending_on_gpu_match_reference(golden_dir, tmp_path):
+    from spearmint_amd.chooser import GPEIChooser, GPEIOptChooser
+    g = _g(golden_dir, "chooser_next_pending.npz")
+    args = (g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=3,pending_samples=9")
+    npr.seed(int(g["g_seed"]))
+    assert ch.next(*args) == int(g["g_job"])
+    assert_ei_close(ch.last_overall_ei, g["g_ei"], rtol=1e-6)
+    os.makedirs(str(tmp_path / "o"), exist_ok=True)
+    op = GPEIOptChooser.init(str(tmp_path / "o"), "mcmc_iters=3,burnin=4,grid_subset=3,pending_samples=8,use_multiprocessing=0")
+    npr.seed(int(g["o_seed"]))
+    job = op.next(*args)
+    if int(g["o_is_new"]):
+        assert isinstance(job, tuple) and job[0] == int(g["o_index"]) and np.allclose(job[1], g["o_point"], atol=1e-5)
+    else:
+        assert job == int(g["o_index"])

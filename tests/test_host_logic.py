@@ -128,9 +128,34 @@ def test_persec_default_semantics_evaluate_all_draws(golden_dir, tmp_path):
     assert isinstance(job, (int, tuple))
 
 
-def test_pending_raises_clearly(golden_dir, tmp_path):
-    g = _g(golden_dir, "branin_c1.npz")
-    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=2")
+def test_gpei_next_with_pending_matches_reference(golden_dir, tmp_path):
+    """Fantasy branch through the plugin API (three jobs still running)."""
+    g = _g(golden_dir, "chooser_next_pending.npz")
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=3,pending_samples=9")
+    eng = OracleEngine(); ch._eng = eng
+    npr.seed(int(g["g_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert job == int(g["g_job"])
+    assert eng.calls == [("ei_run", len(g["candidates"]), 3, 9)]
+    assert np.allclose(ch.last_overall_ei, g["g_ei"], rtol=1e-8, atol=1e-300)
+
+
+def test_opt_next_with_pending_matches_reference(golden_dir, tmp_path):
+    g = _g(golden_dir, "chooser_next_pending.npz")
+    ch = GPEIOptChooser.init(str(tmp_path), "mcmc_iters=3,burnin=4,grid_subset=3,pending_samples=8,use_multiprocessing=0")
+    ch._eng = OracleEngine()
+    npr.seed(int(g["o_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    if int(g["o_is_new"]):
+        assert isinstance(job, tuple) and job[0] == int(g["o_index"])
+        assert np.allclose(job[1], g["o_point"], atol=1e-6)
+    else:
+        assert job == int(g["o_index"])
+
+
+def test_persec_pending_raises_clearly(golden_dir, tmp_path):
+    g = _g(golden_dir, "chooser_next.npz")
+    ch = GPEIperSecChooser.init(str(tmp_path), "mcmc_iters=2,burnin=1,grid_subset=2")
     ch._eng = OracleEngine(); npr.seed(0)
     with pytest.raises(NotImplementedError):
         ch.next(g["grid"], g["values"], g["durations"], g["candidates"][1:], g["candidates"][:1], g["complete"])

@@ -54,6 +54,22 @@ def test_pending_matches_reference(golden_dir):
         _close(ei, g["ei"][:, h], rtol=1e-9)
 
 
+def test_fantasy_half_of_pending_branch(golden_dir):
+    """compute_ei_fantasies (what the GPU path mirrors) + the host fantasy draw
+    reproduce the reference's pending branch."""
+    import scipy.linalg as spla
+    from spearmint_amd import hostgp
+    g = _load(golden_dir, "ei_pending.npz")
+    comp, pend, cand, vals = g["comp"], g["pend"], g["cand"], g["vals"]
+    comp_pend = np.concatenate((comp, pend))
+    for h in range(g["hypers"].shape[0]):
+        chol = orc.posterior(comp_pend, np.concatenate((vals, np.zeros(len(pend)))), g["hypers"][h])[1]
+        fant, bests = hostgp.fantasize_pending(comp, pend, vals, g["hypers"][h], chol[:len(comp), :len(comp)],
+                                               g["randn"][h])
+        ei = orc.compute_ei_fantasies(comp_pend, cand, g["hypers"][h], fant, bests)
+        _close(ei, g["ei"][:, h], rtol=1e-9)
+
+
 def test_persec_matches_reference(golden_dir):
     g = _load(golden_dir, "ei_persec.npz")
     ei = orc.ei_per_s_over_hypers(g["comp"], g["cand"], g["vals"], g["log_durs"],
