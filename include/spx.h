@@ -134,6 +134,9 @@ int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* al
 int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, double* out);
 /* func_m, func_v (M each) of draw `draw`; needs SPX_FLAG_KEEP_MOMENTS.          */
 int spx_get_moments(spx_handle* h, int32_t draw, double* func_m, double* func_v);
+/* exp(predicted log duration) of every candidate under time draw `draw`
+ * (func_time_m, GPEIperSecChooser.py:452-458); needs SPX_FLAG_PER_SEC | SPX_FLAG_KEEP_MOMENTS. */
+int spx_get_time_mean(spx_handle* h, int32_t draw, double* out /* M */);
 /* GP marginal log-likelihood data term  -sum(log diag L) - 0.5 r' K^-1 r  for
  * each resident draw (GPEIChooser.py:281-285): out has H entries, -inf where
  * the covariance is not PD.  Needs spx_set_observations + spx_set_hypers.      */

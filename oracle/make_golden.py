@@ -268,6 +268,19 @@ def gen_chooser_next_pending(mods, tmp):
                    o_index=int(job[0] if isinstance(job, tuple) else job),
                    o_point=np.asarray(job[1] if isinstance(job, tuple) else grid[job]))
         break
+    for seed in range(900, 940):
+        ch = mods["GPEIperSecChooser"].GPEIperSecChooser(tempfile.mkdtemp(prefix="spx_golden_pp_"), mcmc_iters=2,
+                                                         burnin=3, grid_subset=3, pending_samples=6)
+        npr.seed(seed)
+        try:
+            job = ch.next(grid, values, durations, cand, pend, comp)
+        except Exception as e:
+            print("pending persec seed", seed, "reference raised:", e)
+            continue
+        out.update(p_seed=seed, p_is_new=int(isinstance(job, tuple)),
+                   p_index=int(job[0] if isinstance(job, tuple) else job),
+                   p_point=np.asarray(job[1] if isinstance(job, tuple) else grid[job]))
+        break
     np.savez_compressed(os.path.join(OUT, "chooser_next_pending.npz"), grid=grid, values=values,
                         durations=durations, candidates=cand, pending=pend, complete=comp, **out)
 

@@ -15,6 +15,7 @@ from __future__ import absolute_import, print_function
 import os
 
 import numpy as np
+import numpy.random as npr
 import scipy.optimize as spo
 
 from .. import hostgp
@@ -98,17 +99,41 @@ class GPEIperSecChooser(GPEIBase):
 
     # -- the hot path ----------------------------------------------------------------
     def ei_per_s_over_hypers_gpu(self, comp, pend, cand, vals, durs):
-        if pend.shape[0] > 0:
-            raise NotImplementedError("pending-experiment fantasies (GPEIperSecChooser.py:492-548) "
-                                      "are not on the GPU path yet")
         rows, trows = self._paired_samples()
         self._lp_key = None
+        if pend.shape[0] > 0:
+            return self._ei_per_s_with_pending(comp, pend, cand, vals, durs, rows, trows)
         idx, val, mean, draws = self.engine().ei_per_sec_grid(comp, vals, durs, cand, rows, trows,
                                                               want_mean=True, want_draws=False)
         if self.ref_compat:
             # the other mcmc_iters-1 columns of overall_ei stay zero in the reference
             mean = mean / float(self.mcmc_iters)
         return idx, mean
+
+    def _ei_per_s_with_pending(self, comp, pend, cand, vals, durs, rows, trows):
+        """Pending branch (:492-548): EI averaged over fantasies (objective GP over
+        [comp; pend], GPU) divided by the predicted duration (time GP over comp only,
+        GPU).  The two GPs have different observation sets, so they are two engine
+        passes; the final M x H division, mean and argmax are a tiny host step."""
+        from ..engine import FLAG_KEEP_MOMENTS, FLAG_PER_SEC
+        eng = self.engine()
+        H = rows.shape[0]
+        # pass 1: durations.  The fantasy normals are drawn first, where the reference
+        # consumes the RNG (once per evaluated draw, :523).
+        randn = [npr.randn(pend.shape[0], int(self.pending_samples)) for _ in range(H)]
+        eng.set_observations(comp, vals)
+        eng.set_candidates(cand)
+        eng.set_hypers(rows)
+        eng.set_time_model(durs, trows)
+        eng.factor()
+        eng.ei_run(FLAG_PER_SEC | FLAG_KEEP_MOMENTS)
+        time_m = np.stack([eng.get_time_mean(h) for h in range(H)], axis=1)
+        # pass 2: EI averaged over fantasies
+        _, _, ei = self._ei_with_pending_gpu(comp, pend, cand, vals, rows, randn, True)
+        overall = np.zeros((cand.shape[0], self.mcmc_iters))
+        overall[:, :H] = ei / time_m
+        mean = np.mean(overall, axis=1)
+        return int(np.argmax(mean)), mean
 
     def _refine(self, points, comp, vals, durs):
         rows, trows = (self.hyper_samples[:self.mcmc_iters],

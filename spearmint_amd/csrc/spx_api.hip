@@ -84,7 +84,7 @@ struct spx_handle {
 
     DevBuf comp, vals, ldur, cand, hyp, htab;
     DevBuf Xs, X2s, s1, Lm, WT, Dinv, gamma, alpha, info, lp;
-    DevBuf Cs[2], s2[2], Kst[2], part_ss[2], part_bg[2], time_m[2], ei_draw, ei_mean, mom_m, mom_v;
+    DevBuf Cs[2], s2[2], Kst[2], part_ss[2], part_bg[2], time_m[2], ei_draw, ei_mean, mom_m, mom_v, mom_t;
     DevBuf am_val, am_idx, am_out_val, am_out_idx, scratch;
     // pending-experiment fantasies (spx_set_fantasies): S right-hand sides per draw
     int S = 0;
@@ -192,7 +192,7 @@ void spx_destroy(spx_handle* h)
                           &h->Cs[0], &h->s2[0], &h->Kst[0], &h->part_ss[0], &h->part_bg[0], &h->time_m[0],
                           &h->Cs[1], &h->s2[1], &h->Kst[1], &h->part_ss[1], &h->part_bg[1], &h->time_m[1],
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
-                          &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->am_val, &h->am_idx,
+                          &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
                           &h->am_out_val, &h->am_out_idx, &h->scratch};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -499,6 +499,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
     if (keep_mom) {
         if ((rc = h->mom_m.reserve((size_t)H * Mp * 8))) return rc;
         if ((rc = h->mom_v.reserve((size_t)H * Mp * 8))) return rc;
+        if (per_sec && (rc = h->mom_t.reserve((size_t)H * Mp * 8))) return rc;
     }
     const int nab = argmax_blocks(M);
     if ((rc = h->am_val.reserve((size_t)nab * 8))) return rc;
@@ -535,6 +536,9 @@ int spx_ei_run(spx_handle* h, int32_t flags)
                                                    h->htab.d() + (size_t)H * SPX_HT, h->alpha.d() + (size_t)H * Np, tm,
                                                    (int)N, Np, mc, Dp, H));
         }
+        if (per_sec && keep_mom)   // predicted durations [H][mc] -> [H][Mp] for spx_get_time_mean
+            HIPCHK(hipMemcpy2DAsync(h->mom_t.d() + c0, (size_t)Mp * 8, tm, (size_t)mc * 8,
+                                    (size_t)std::min<int64_t>(mc, Mp - c0) * 8, (size_t)H, hipMemcpyDeviceToDevice, s));
         // 2 * cand / ls and |cand / ls|^2 for every draw (one launch per chunk)
         TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls, hs, H, 2.0, Cs, s2));
         if (ns == 2) {
@@ -636,6 +640,18 @@ int spx_get_moments(spx_handle* h, int32_t draw, double* func_m, double* func_v)
     const int64_t Mp = round_up(h->M, SPX_BN);
     if (func_m) HIPCHK(hipMemcpy(func_m, h->mom_m.d() + (size_t)draw * Mp, (size_t)h->M * 8, hipMemcpyDeviceToHost));
     if (func_v) HIPCHK(hipMemcpy(func_v, h->mom_v.d() + (size_t)draw * Mp, (size_t)h->M * 8, hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
+int spx_get_time_mean(spx_handle* h, int32_t draw, double* out)
+{
+    if (!h || !out || !h->ran || !h->ran_moments || h->nmodels != 2)
+        return fail(SPX_ERR_ARG, "spx_get_time_mean: run spx_ei_run with SPX_FLAG_PER_SEC | SPX_FLAG_KEEP_MOMENTS first");
+    if (draw < 0 || draw >= h->H) return fail(SPX_ERR_ARG, "spx_get_time_mean: draw out of range");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int64_t Mp = round_up(h->M, SPX_BN);
+    HIPCHK(hipMemcpy(out, h->mom_t.d() + (size_t)draw * Mp, (size_t)h->M * 8, hipMemcpyDeviceToHost));
     return SPX_OK;
 }
 

@@ -58,6 +58,7 @@ ABI = {
     "spx_get_factor": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p]),
     "spx_get_cross_cov": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
     "spx_get_moments": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p, _c_double_p]),
+    "spx_get_time_mean": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p]),
     "spx_gp_logprob": (ctypes.c_int, [_vp, _c_double_p]),
     "spx_not_pd_info": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p]),
     "spx_get_timings": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p, ctypes.c_int]),
@@ -278,6 +279,11 @@ class Engine(object):
         m = np.empty(self.M); v = np.empty(self.M)
         self._check(self._lib.spx_get_moments(self._h, int(draw), _dp(m), _dp(v)))
         return m, v
+
+    def get_time_mean(self, draw):
+        out = np.empty(self.M)
+        self._check(self._lib.spx_get_time_mean(self._h, int(draw), _dp(out)))
+        return out
 
     def gp_logprob(self, raise_not_pd=False):
         """Data term of the GP log posterior for every resident draw

@@ -22,6 +22,16 @@ class OracleEngine(object):
     def set_hypers(self, hypers):
         self.hypers, self.fant = np.atleast_2d(hypers), None
 
+    def set_time_model(self, log_durs, time_hypers):
+        self.log_durs, self.time_hypers = np.asarray(log_durs, float), np.atleast_2d(time_hypers)
+
+    def get_time_mean(self, draw):
+        import scipy.linalg as spla
+        t_mean, t_noise, t_amp2, t_ls = orc.unpack_hyper(self.time_hypers[draw])
+        chol = spla.cholesky(orc.cov(t_amp2, t_ls, self.comp) + t_noise * np.eye(len(self.comp)), lower=True)
+        t_alpha = spla.cho_solve((chol, True), self.log_durs - t_mean)
+        return np.exp(np.dot(orc.cov(t_amp2, t_ls, self.comp, self.cand).T, t_alpha) + t_mean)
+
     def factor(self):
         self.chols = [orc.posterior(self.comp, self.vals, h)[1] for h in self.hypers]
 

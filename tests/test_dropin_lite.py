@@ -81,6 +81,11 @@ def test_unmodified_lite_loop_drives_our_chooser(lite, method, margs):
         assert len(x) == 2 and all(0.0 <= v <= 1.0 for v in x)
         lines[-1] = "%f 1.5 %s" % (_branin(x), " ".join(lines[-1].split()[2:]))   # job "finished"
         open(res, "w").write("\n".join(lines) + "\n")
+    # two proposals in one call: the second one sees the first as PENDING (fantasy branch)
+    opts.num_jobs = 2
+    mod.main_controller(opts, [expt])
+    lines = open(res).read().strip().split("\n")
+    assert lines[-1].startswith("P P ") and lines[-2].startswith("P P ") and lines[-1] != lines[-2]
     # our module was the one loaded, under the reference's name, and it persisted state under that name
     ch = sys.modules["chooser." + method]
     assert "dropin" in ch.__file__

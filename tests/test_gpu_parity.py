@@ -405,3 +405,12 @@ def test_choosers_with_pending_on_gpu_match_reference(golden_dir, tmp_path):
         assert isinstance(job, tuple) and job[0] == int(g["o_index"]) and np.allclose(job[1], g["o_point"], atol=1e-5)
     else:
         assert job == int(g["o_index"])
+    os.makedirs(str(tmp_path / "p"), exist_ok=True)
+    from spearmint_amd.chooser import GPEIperSecChooser
+    ps = GPEIperSecChooser.init(str(tmp_path / "p"), "mcmc_iters=2,burnin=3,grid_subset=3,pending_samples=6,ref_compat=1")
+    npr.seed(int(g["p_seed"]))
+    job = ps.next(*args)
+    if int(g["p_is_new"]):
+        assert isinstance(job, tuple) and job[0] == int(g["p_index"]) and np.allclose(job[1], g["p_point"], atol=1e-5)
+    else:
+        assert job == int(g["p_index"])

@@ -153,12 +153,17 @@ def test_opt_next_with_pending_matches_reference(golden_dir, tmp_path):
         assert job == int(g["o_index"])
 
 
-def test_persec_pending_raises_clearly(golden_dir, tmp_path):
-    g = _g(golden_dir, "chooser_next.npz")
-    ch = GPEIperSecChooser.init(str(tmp_path), "mcmc_iters=2,burnin=1,grid_subset=2")
-    ch._eng = OracleEngine(); npr.seed(0)
-    with pytest.raises(NotImplementedError):
-        ch.next(g["grid"], g["values"], g["durations"], g["candidates"][1:], g["candidates"][:1], g["complete"])
+def test_persec_next_with_pending_matches_reference(golden_dir, tmp_path):
+    g = _g(golden_dir, "chooser_next_pending.npz")
+    ch = GPEIperSecChooser.init(str(tmp_path), "mcmc_iters=2,burnin=3,grid_subset=3,pending_samples=6,ref_compat=1")
+    ch._eng = OracleEngine()
+    npr.seed(int(g["p_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    if int(g["p_is_new"]):
+        assert isinstance(job, tuple) and job[0] == int(g["p_index"])
+        assert np.allclose(job[1], g["p_point"], atol=1e-6)
+    else:
+        assert job == int(g["p_index"])
 
 
 def test_unsupported_covariance_rejected(tmp_path):
