@@ -141,6 +141,11 @@ int spx_get_time_mean(spx_handle* h, int32_t draw, double* out /* M */);
  * each resident draw (GPEIChooser.py:281-285): out has H entries, -inf where
  * the covariance is not PD.  Needs spx_set_observations + spx_set_hypers.      */
 int spx_gp_logprob(spx_handle* h, double* out);
+/* Objective of the local refinement (GPEIOptChooser.py:360-440; "next" row 3): at ONE point
+ * (D doubles) the summed negative EI over the resident draws and its gradient, in the
+ * reference's scaling (its grad_xp carries a factor one half).  Needs spx_factor or a
+ * previous spx_ei_grid; observations without pending experiments.                       */
+int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad /* D */);
 /* which draw / pivot failed in the last SPX_ERR_NOT_PD                         */
 int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot);
 

@@ -115,22 +115,31 @@ class GPEIOptChooser(GPEIBase):
         return out
 
     def _refine(self, points, comp, vals, pend):
-        if pend.shape[0] > 0:
-            models = []
-            for h in self.hyper_samples:
-                npr.set_state(self.randomstate)
-                models.append(hostgp.PendingPointModel(comp, pend, vals, h,
-                                                       npr.randn(pend.shape[0], self.pending_samples)))
-        else:
-            models = [hostgp.PointModel(comp, vals, h) for h in self.hyper_samples]
+        """L-BFGS-B on the summed EI of each kept point (:285-289).  Objective and
+        gradient come from the GPU (spx_ei_grad, against the factorisation the first
+        EI pass left resident) or, for tiny problems / pending jobs, from host models."""
+        if pend.shape[0] == 0 and self._use_gpu_refine(comp.shape[0]):
+            eng = self.engine()
 
-        def objective(x):
-            total, grad = 0.0, np.zeros(x.shape[0])
-            for m in models:
-                e, g = m.neg_ei_and_grad(x)
-                total += e
-                grad = grad + g
-            return total, grad
+            def objective(x):
+                return eng.ei_grad(x)
+        else:
+            if pend.shape[0] > 0:
+                models = []
+                for h in self.hyper_samples:
+                    npr.set_state(self.randomstate)
+                    models.append(hostgp.PendingPointModel(comp, pend, vals, h,
+                                                           npr.randn(pend.shape[0], self.pending_samples)))
+            else:
+                models = [hostgp.PointModel(comp, vals, h) for h in self.hyper_samples]
+
+            def objective(x):
+                total, grad = 0.0, np.zeros(x.shape[0])
+                for m in models:
+                    e, g = m.neg_ei_and_grad(x)
+                    total += e
+                    grad = grad + g
+                return total, grad
 
         bounds = [(0, 1)] * comp.shape[1]
         out = np.array(points, dtype=float, copy=True)

@@ -47,7 +47,7 @@ class GPEIBase(object):
     state_keys = ("dims", "ls", "amp2", "noise", "mean")
 
     def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
-                 noiseless=False, device=0, lib=None, gpu_logprob="auto", **unused):
+                 noiseless=False, device=0, lib=None, gpu_logprob="auto", gpu_refine="auto", **unused):
         if covar != "Matern52":
             # the HIP path implements the ARD Matern-5/2 kernel named by the north star
             raise ValueError("spearmint_amd choosers support covar=Matern52 only (got %r)" % (covar,))
@@ -63,6 +63,8 @@ class GPEIBase(object):
         # "0" host numpy/scipy (the reference's way), "1" libspx on the GPU, "auto" = GPU once
         # the factorisation outweighs the launch latency (N >= 64: 0.36 ms vs 1.1 ms on the host; 11 ms vs 250 ms at N=2048)
         self.gpu_logprob = str(gpu_logprob)
+        # same choice for the EI + gradient objective of the local refinement (spx_ei_grad)
+        self.gpu_refine = str(gpu_refine)
         self._lp_key = None
         self.D = -1
         self._eng = None          # created lazily in next(): never before a fork, never pickled
@@ -126,6 +128,11 @@ class GPEIBase(object):
         if self.gpu_logprob == "auto":
             return n >= 64
         return _as_bool(self.gpu_logprob)
+
+    def _use_gpu_refine(self, n):
+        if self.gpu_refine == "auto":
+            return n >= 64
+        return _as_bool(self.gpu_refine)
 
     def data_logprob(self, comp, vals, mean, amp2, noise, ls):
         """-sum log diag L - 0.5 r'K^-1 r (GPEIChooser.py:281-285).  The slice sampler's

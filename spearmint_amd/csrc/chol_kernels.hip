@@ -289,12 +289,13 @@ __global__ __launch_bounds__(256) void k_gamma(const double* __restrict__ WT, si
                                                const double* __restrict__ htab, int htab_stride,
                                                double* __restrict__ gamma, int N, int Np)
 {
+    // htab == nullptr: plain product W * rhs (no mean subtraction)
     // batch entry b = blockIdx.y: its own right-hand side, and (strides permitting) its own W / mean
     __shared__ double r[256];
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const double* Wh = WT + (size_t)b * wt_stride;
-    const double mean = htab[b * htab_stride + 0];
+    const double mean = htab ? htab[b * htab_stride + 0] : 0.0;
     const double* vh = vals + (size_t)b * vals_stride;
     double acc = 0.0;
     const int jmax = blockIdx.x * 256 + 255;  // rows this block needs: j <= i
@@ -315,6 +316,13 @@ void launch_gamma(hipStream_t s, const double* WT, const double* vals, const dou
     // one right-hand side (vals) shared by nh draws, each with its own W and mean
     hipLaunchKernelGGL(k_gamma, dim3(Np / 256 + (Np % 256 != 0), nh), dim3(256), 0, s, WT,
                        (size_t)Np * Np, vals, (size_t)0, htab, SPX_HT, gamma, N, Np);
+}
+
+// t_h = W_h rhs_h for nh draws, rhs [nh][Np] (pad rows must be zero)
+void launch_gemv_lower(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh)
+{
+    hipLaunchKernelGGL(k_gamma, dim3(Np / 256 + (Np % 256 != 0), nh), dim3(256), 0, s, WT,
+                       (size_t)Np * Np, rhs, (size_t)Np, (const double*)nullptr, 0, out, Np, Np);
 }
 
 // S right-hand sides (fantasy columns, [S][n] contiguous) against ONE draw's W and mean

@@ -46,11 +46,21 @@ void launch_gamma(hipStream_t s, const double* WT, const double* vals, const dou
                   double* gamma, int N, int Np, int nh);
 void launch_gamma_multi(hipStream_t s, const double* WT_h, const double* rhs, const double* htab_h,
                         double* gamma, int N, int Np, int S);
+void launch_gemv_lower(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh);
 void launch_alpha(hipStream_t s, const double* WT, const double* gamma, double* alpha, int Np, int nh);
 void launch_fwd_solve(hipStream_t s, const double* L, const double* Dinv, const double* vals,
                       const double* htab, double* gamma, int N, int Np, int nh);
 void launch_logprob(hipStream_t s, const double* L, const double* gamma, const int* info,
                     double* out, int Np, int nh);
+
+// refine_kernels.hip
+void launch_point_cov(hipStream_t s, const double* Xs, const double* s1, const double* hyp,
+                      const double* htab, const double* x, double* kvec, double* dkdr2, int N, int Np,
+                      int D, int Dp, int nh);
+void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, const double* htab,
+                         const double* alpha, const double* kvec, const double* dkdr2,
+                         const double* tvec, const double* zvec, const double* x, double best,
+                         double* out, int N, int Np, int D, int Dp, int nh);
 
 // predict_kernels.hip
 void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,

@@ -89,6 +89,7 @@ struct spx_handle {
     // pending-experiment fantasies (spx_set_fantasies): S right-hand sides per draw
     int S = 0;
     DevBuf fantT, gammaS, bests, part_bgS[2];
+    DevBuf pt_x, pt_k, pt_dk, pt_t, pt_z, pt_out;   // spx_ei_grad work vectors
 
     double best_val = 0.0;
     int64_t best_idx = -1;
@@ -192,6 +193,7 @@ void spx_destroy(spx_handle* h)
                           &h->Cs[0], &h->s2[0], &h->Kst[0], &h->part_ss[0], &h->part_bg[0], &h->time_m[0],
                           &h->Cs[1], &h->s2[1], &h->Kst[1], &h->part_ss[1], &h->part_bg[1], &h->time_m[1],
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
+                          &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
                           &h->am_out_val, &h->am_out_idx, &h->scratch};
         for (DevBuf* b : bufs) b->release();
@@ -760,6 +762,44 @@ int spx_ei_per_sec_grid(spx_handle* h, const double* comp, const double* vals, c
     if (!h || !log_durs || !time_hypers) return fail(SPX_ERR_ARG, "spx_ei_per_sec_grid: null argument");
     return run_grid(h, comp, vals, log_durs, N, D, cand, M, hypers, time_hypers, H, flags | SPX_FLAG_PER_SEC,
                     ei_mean_out, ei_draw_out, best_idx, best_val);
+}
+
+int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad)
+{
+    if (!h || !point || !neg_ei_sum || !grad) return fail(SPX_ERR_ARG, "spx_ei_grad: null argument");
+    if (!h->factored) return fail(SPX_ERR_ARG, "spx_ei_grad: call spx_factor (or spx_ei_grid) first");
+    if (h->S > 0) return fail(SPX_ERR_ARG, "spx_ei_grad: not available with fantasies set");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int H = h->H, D = h->D, Dp = h->Dp, Np = h->Np;
+    const int64_t N = h->N;
+    if ((rc = h->pt_x.reserve((size_t)D * 8))) return rc;
+    if ((rc = h->pt_k.reserve((size_t)H * Np * 8))) return rc;
+    if ((rc = h->pt_dk.reserve((size_t)H * Np * 8))) return rc;
+    if ((rc = h->pt_t.reserve((size_t)H * Np * 8))) return rc;
+    if ((rc = h->pt_z.reserve((size_t)H * Np * 8))) return rc;
+    if ((rc = h->pt_out.reserve((size_t)H * (1 + D) * 8))) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->pt_x.p, point, (size_t)D * 8, hipMemcpyHostToDevice, s));
+    launch_point_cov(s, h->Xs.d(), h->s1.d(), h->hyp.d(), h->htab.d(), h->pt_x.d(), h->pt_k.d(), h->pt_dk.d(),
+                     (int)N, Np, D, Dp, H);
+    launch_gemv_lower(s, h->WT.d(), h->pt_k.d(), h->pt_t.d(), Np, H);       // t = W k
+    launch_alpha(s, h->WT.d(), h->pt_t.d(), h->pt_z.d(), Np, H);            // z = W^T t = K^-1 k
+    launch_point_finish(s, h->Xs.d(), h->hyp.d(), h->htab.d(), h->alpha.d(), h->pt_k.d(), h->pt_dk.d(),
+                        h->pt_t.d(), h->pt_z.d(), h->pt_x.d(), h->best, h->pt_out.d(), (int)N, Np, D, Dp, H);
+    std::vector<double> out((size_t)H * (1 + D));
+    HIPCHK(hipMemcpyAsync(out.data(), h->pt_out.p, out.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    // sum over draws in draw order, as grad_optimize_ei_over_hypers does (:368-380)
+    double f = 0.0;
+    for (int d = 0; d < D; ++d) grad[d] = 0.0;
+    for (int i = 0; i < H; ++i) {
+        f += -out[(size_t)i * (1 + D)];
+        for (int d = 0; d < D; ++d) grad[d] = grad[d] + out[(size_t)i * (1 + D) + 1 + d];
+    }
+    *neg_ei_sum = f;
+    return SPX_OK;
 }
 
 int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n)

@@ -60,6 +60,7 @@ ABI = {
     "spx_get_moments": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p, _c_double_p]),
     "spx_get_time_mean": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p]),
     "spx_gp_logprob": (ctypes.c_int, [_vp, _c_double_p]),
+    "spx_ei_grad": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p]),
     "spx_not_pd_info": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p]),
     "spx_get_timings": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p, ctypes.c_int]),
     "spx_timing_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -297,6 +298,17 @@ class Engine(object):
             if draw >= 0:
                 raise LinAlgError("%d-th leading minor of the array is not positive definite" % (pivot + 1))
         return out
+
+    def ei_grad(self, point):
+        """(-sum_h EI_h(x), gradient) at one point for the resident factorisation --
+        the L-BFGS objective of GPEIOptChooser.py:360-388."""
+        x = _f64(point).ravel()
+        if x.shape[0] != self.D:
+            raise ValueError("point must have D entries")
+        f = ctypes.c_double(0.0)
+        g = np.empty(self.D)
+        self._check(self._lib.spx_ei_grad(self._h, _dp(x), ctypes.byref(f), _dp(g)))
+        return float(f.value), g
 
     def not_pd_info(self):
         d = ctypes.c_int32(-1); p = ctypes.c_int32(-1)

@@ -64,10 +64,20 @@ class OracleEngine(object):
 
     def ei_grid(self, comp, vals, cand, hypers, want_mean=True, want_draws=False, flags=0):
         ei = orc.ei_over_hypers(comp, cand, vals, hypers)
+        self._last_comp, self._last_vals, self._last_rows = comp, vals, np.atleast_2d(hypers)
         mean = np.mean(ei, axis=1)
         idx = int(np.argmax(mean))
         self.calls.append(("ei_grid", cand.shape[0], np.atleast_2d(hypers).shape[0]))
         return idx, float(mean[idx]), mean, (ei if want_draws else None)
+
+    def ei_grad(self, x):
+        from spearmint_amd import hostgp
+        total, grad = 0.0, np.zeros(len(x))
+        for h in self._last_rows:
+            e, g = hostgp.PointModel(self._last_comp, self._last_vals, (h[0], h[1], h[2], h[3:])).neg_ei_and_grad(x)
+            total += e
+            grad = grad + g
+        return total, grad
 
     def ei_per_sec_grid(self, comp, vals, log_durs, cand, hypers, time_hypers,
                         want_mean=True, want_draws=False, flags=0):

@@ -414,3 +414,39 @@ def test_choosers_with_pending_on_gpu_match_reference(golden_dir, tmp_path):
         assert isinstance(job, tuple) and job[0] == int(g["p_index"]) and np.allclose(job[1], g["p_point"], atol=1e-5)
     else:
         assert job == int(g["p_index"])
+
+
+# ---- local refinement objective ("next" row 3): EI and gradient at a point on the GPU ------------
+@pytest.mark.parametrize("N,D,H,seed", [(40, 2, 3, 51), (300, 7, 4, 52), (1000, 32, 3, 53)])
+def test_ei_grad_matches_host_model(eng, N, D, H, seed):
+    from spearmint_amd import hostgp
+    comp, cand, vals, hypers = synthetic_problem(N, 50, D, H, seed)
+    eng.ei_grid(comp, vals, cand, hypers)            # leaves observations, draws and factors resident
+    models = [hostgp.PointModel(comp, vals, (h[0], h[1], h[2], h[3:])) for h in hypers]
+    rs = np.random.RandomState(seed)
+    for x in [cand[3], comp[5] + 1e-3 * rs.randn(D), rs.rand(D)]:
+        f_ref, g_ref = 0.0, np.zeros(D)
+        for m in models:
+            e, g = m.neg_ei_and_grad(x)
+            f_ref += e; g_ref = g_ref + g
+        f, g = eng.ei_grad(x)
+        assert np.isclose(f, f_ref, rtol=1e-7, atol=1e-300)
+        assert np.allclose(g, g_ref, rtol=1e-6, atol=1e-9 * np.abs(g_ref).max())
+    # and it is the gradient of what it says (central differences, reference scaling = 1/2)
+    x = cand[7].copy()
+    f0, g = eng.ei_grad(x)
+    for d in range(min(D, 3)):
+        e = np.zeros(D); e[d] = 1e-6
+        num = (eng.ei_grad(x + e)[0] - eng.ei_grad(x - e)[0]) / 2e-6
+        assert np.isclose(0.5 * num, g[d], rtol=2e-3, atol=1e-9)
+
+
+def test_opt_chooser_with_gpu_refinement_matches_reference(golden_dir, tmp_path):
+    from spearmint_amd.chooser import GPEIOptChooser
+    g = _g(golden_dir, "chooser_next.npz")
+    ch = GPEIOptChooser.init(str(tmp_path), "mcmc_iters=4,burnin=6,grid_subset=5,use_multiprocessing=0,"
+                                            "gpu_refine=1,gpu_logprob=1")
+    npr.seed(int(g["opt_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert isinstance(job, tuple) and job[0] == int(g["opt_index"])
+    assert np.allclose(job[1], g["opt_point"], atol=1e-5)
