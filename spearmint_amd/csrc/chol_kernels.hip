@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
 
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh)
 {
-    const size_t lds = (size_t)(NB * LDP + 2 * NB * LDS_S) * sizeof(double);
+    const size_t lds = (size_t)(NB * LDP + 2 * NB * LDS_S) * sizeof(double);   // 100 KB > the 64 KB default
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k);
 }
 
@@ -208,7 +210,9 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 {
     const int nblk = Np / NB;
     if (nblk - k - 1 <= 0) return;
-    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);
+    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);                // 67.6 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_panel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k - 1, nh), dim3(256), lds, s, L, Dinv, Np, k);
 }
 
@@ -278,6 +282,8 @@ __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
 void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh)
 {
     const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trinv),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_trinv, dim3(Np / NB, nh), dim3(256), lds, s, L, Dinv, WT, Np);
 }
 
@@ -409,12 +415,8 @@ void launch_fwd_solve(hipStream_t s, const double* L, const double* Dinv, const 
                       const double* htab, double* gamma, int N, int Np, int nh)
 {
     const size_t lds = (size_t)(Np + NB) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_solve),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_solve),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k_fwd_solve, dim3(nh), dim3(256), lds, s, L, Dinv, vals, htab, gamma, N, Np);
 }
 

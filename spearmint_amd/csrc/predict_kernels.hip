@@ -206,12 +206,9 @@ void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, con
 {
     const int ncb = Mc / BN, nrb = Np / BM;
     const size_t lds = (size_t)(4 * BK * LDT) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // per launch (not cached): the attribute is per device, and one process may drive several GPUs
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int grid = 8 * ((ncb + 7) / 8) * nrb * nh;
     hipLaunchKernelGGL(k_predict_gemm, dim3(grid), dim3(256), lds, s, WT, Kst, gamma,
                        part_ss, part_bg, Np, Mc, nh, ncb, nrb, gammaS, S, part_bgS);

@@ -450,3 +450,44 @@ def test_opt_chooser_with_gpu_refinement_matches_reference(golden_dir, tmp_path)
     job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
     assert isinstance(job, tuple) and job[0] == int(g["opt_index"])
     assert np.allclose(job[1], g["opt_point"], atol=1e-5)
+
+
+def test_c5_shard_per_second_properties(eng):
+    """BASELINE config 5 per-GPU shard: dual GP (objective + log-duration), 16-D,
+    N_obs=1024, 62 500 candidates, 20 draws."""
+    N, M, D, H = 1024, 62500, 16, 20
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(N, M, D, H, 5000, per_sec=True)
+    idx, val, mean, draws = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+    assert np.array_equal(mean, np.mean(draws, axis=1)) and idx == int(np.argmax(mean))
+    sub = np.r_[0:10, np.random.RandomState(1).choice(M, 290, replace=False), idx]
+    ref = orc.ei_per_s_over_hypers(comp, cand[sub], vals, log_durs, hypers, th)
+    assert_ei_close(draws[sub], ref, rtol=1e-6)
+    # EI/s = EI / predicted duration: dividing out the plain EI recovers exp(time mean) > 0
+    plain = eng.ei_grid(comp, vals, cand[sub], hypers, want_draws=True)[3]
+    ok = plain > 1e-200
+    assert np.all(plain[ok] / draws[sub][ok] > 0)
+
+
+def test_c4_shard_properties_and_two_shards(eng):
+    """BASELINE config 4: the candidate grid sharded contiguously; two of the eight
+    125k-candidate shards scored one after the other and combined by the all-reduce rule."""
+    N, D, H, Ms = 2048, 32, 20, 125000
+    comp, _, vals, hypers = synthetic_problem(N, 16, D, H, 4000, near=0)
+    eng.set_observations(comp, vals); eng.set_hypers(hypers); eng.factor()
+    recs, keep = [], []
+    for r in range(2):
+        shard = np.random.RandomState(4000 + r).rand(Ms, D)
+        eng.set_candidates(shard, index_base=r * Ms)
+        eng.ei_run()
+        i, v = eng.best()
+        m = eng.ei_mean()
+        assert r * Ms <= i < (r + 1) * Ms and v == m[i - r * Ms] == m.max()
+        recs.append([v, i]); keep.append((shard, m))
+    gi, gv = sd.pick_best(recs)
+    allm = np.concatenate([k[1] for k in keep])
+    assert gi == int(np.argmax(allm)) and gv == allm.max()
+    # oracle spot check on the winning shard
+    shard, m = keep[gi // Ms]
+    sub = np.r_[gi % Ms, 0:63]
+    ref = orc.ei_over_hypers(comp, shard[sub], vals, hypers)
+    assert np.allclose(m[sub], np.mean(ref, axis=1), rtol=1e-6, atol=1e-300)
