@@ -47,7 +47,8 @@ class GPEIBase(object):
     state_keys = ("dims", "ls", "amp2", "noise", "mean")
 
     def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
-                 noiseless=False, device=0, lib=None, gpu_logprob="auto", gpu_refine="auto", **unused):
+                 noiseless=False, device=0, ndev=1, lib=None, gpu_logprob="auto", gpu_refine="auto",
+                 **unused):
         if covar != "Matern52":
             # the HIP path implements the ARD Matern-5/2 kernel named by the north star
             raise ValueError("spearmint_amd choosers support covar=Matern52 only (got %r)" % (covar,))
@@ -58,6 +59,7 @@ class GPEIBase(object):
         self.pending_samples = int(pending_samples)
         self.noiseless = _as_bool(noiseless)
         self.device = int(device)
+        self.ndev = int(ndev)     # GPUs device .. device+ndev-1, candidates sharded over them
         self.lib_path = lib
         # where the slice sampler's log-likelihood (K build + Cholesky + solve per call) runs:
         # "0" host numpy/scipy (the reference's way), "1" libspx on the GPU, "auto" = GPU once
@@ -73,8 +75,11 @@ class GPEIBase(object):
     # -- GPU handle -----------------------------------------------------------
     def engine(self):
         if self._eng is None:
-            from ..engine import Engine
-            self._eng = Engine(self.device, self.lib_path)
+            from ..engine import Engine, MultiEngine
+            if self.ndev > 1:
+                self._eng = MultiEngine(range(self.device, self.device + self.ndev), self.lib_path)
+            else:
+                self._eng = Engine(self.device, self.lib_path)
         return self._eng
 
     def __getstate__(self):

@@ -331,3 +331,121 @@ class Engine(object):
 def device_count(lib=None):
     n = load_library(lib).spx_device_count()
     return n if n > 0 else 0
+
+
+class MultiEngine(object):
+    """Several GPUs driven from ONE process (the unmodified Spearmint driver is a
+    single process): candidates are sharded contiguously over `devices`, each shard
+    is scored by its own Engine on its own host thread (ctypes releases the GIL
+    while libspx runs), observations / hyper draws are replicated, and the per-shard
+    (best value, global index) records are combined with the numpy argmax rule --
+    the same decomposition as the one-process-per-GPU path of bench.py, minus the
+    collective (the records already live in one address space).
+
+    Same surface as Engine for what the choosers call."""
+
+    def __init__(self, devices, lib=None):
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise ValueError("MultiEngine needs at least one device")
+        self.engines = [Engine(d, lib) for d in self.devices]
+        self.N = self.M = self.D = self.H = 0
+        self._bounds = []
+
+    # the single-point / single-stream calls go to the first engine
+    def __getattr__(self, name):
+        if name in ("gp_logprob", "ei_grad", "get_factor", "not_pd_info", "timings", "get_cross_cov"):
+            return getattr(self.engines[0], name)
+        raise AttributeError(name)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def _each(self, fn):
+        import threading
+        out = [None] * len(self.engines)
+        err = []
+
+        def run(i):
+            try:
+                out[i] = fn(i, self.engines[i])
+            except BaseException as ex:  # re-raised in the caller's thread
+                err.append(ex)
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(self.engines))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    def set_observations(self, comp, vals):
+        comp = _f64(comp); vals = _f64(vals).ravel()
+        self.N, self.D = comp.shape
+        self._each(lambda i, e: e.set_observations(comp, vals))
+
+    def set_hypers(self, hypers):
+        hypers = _f64(np.atleast_2d(hypers))
+        self.H = hypers.shape[0]
+        self._each(lambda i, e: e.set_hypers(hypers))
+
+    def set_time_model(self, log_durs, time_hypers):
+        self._each(lambda i, e: e.set_time_model(log_durs, time_hypers))
+
+    def set_option(self, name, value):
+        self._each(lambda i, e: e.set_option(name, value))
+
+    def set_candidates(self, cand, index_base=0):
+        from .dist import shard_bounds
+        cand = _f64(cand)
+        self.M = cand.shape[0]
+        P = min(len(self.engines), self.M)
+        self._bounds = [shard_bounds(self.M, P, r) for r in range(P)]
+        self._base = int(index_base)
+        self._each(lambda i, e: e.set_candidates(cand[self._bounds[i][0]:self._bounds[i][1]],
+                                                 index_base + self._bounds[i][0]) if i < P else None)
+
+    def factor(self):
+        self._each(lambda i, e: e.factor())
+
+    def set_fantasies(self, fant, bests):
+        self._each(lambda i, e: e.set_fantasies(fant, bests))
+
+    def ei_run(self, flags=0):
+        self._each(lambda i, e: e.ei_run(flags) if i < len(self._bounds) else None)
+
+    def best(self):
+        from .dist import pick_best
+        recs = [list(self.engines[i].best()[::-1]) for i in range(len(self._bounds))]
+        return pick_best(recs)
+
+    def ei_mean(self):
+        return np.concatenate([self.engines[i].ei_mean() for i in range(len(self._bounds))])
+
+    def ei_draws(self):
+        return np.vstack([self.engines[i].ei_draws() for i in range(len(self._bounds))])
+
+    def get_time_mean(self, draw):
+        return np.concatenate([self.engines[i].get_time_mean(draw) for i in range(len(self._bounds))])
+
+    def ei_grid(self, comp, vals, cand, hypers, want_mean=True, want_draws=False, flags=0):
+        self.set_observations(comp, vals)
+        self.set_candidates(cand)
+        self.set_hypers(hypers)
+        self.factor()
+        self.ei_run(flags)
+        idx, val = self.best()
+        return idx, val, (self.ei_mean() if want_mean else None), (self.ei_draws() if want_draws else None)
+
+    def ei_per_sec_grid(self, comp, vals, log_durs, cand, hypers, time_hypers,
+                        want_mean=True, want_draws=False, flags=0):
+        self.set_observations(comp, vals)
+        self.set_candidates(cand)
+        self.set_hypers(hypers)
+        self.set_time_model(log_durs, time_hypers)
+        self.factor()
+        self.ei_run(flags | FLAG_PER_SEC)
+        idx, val = self.best()
+        return idx, val, (self.ei_mean() if want_mean else None), (self.ei_draws() if want_draws else None)

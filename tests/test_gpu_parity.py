@@ -491,3 +491,28 @@ def test_c4_shard_properties_and_two_shards(eng):
     sub = np.r_[gi % Ms, 0:63]
     ref = orc.ei_over_hypers(comp, shard[sub], vals, hypers)
     assert np.allclose(m[sub], np.mean(ref, axis=1), rtol=1e-6, atol=1e-300)
+
+
+def test_multi_engine_matches_single(eng):
+    """Several engines in one process (here: two handles on the one GPU of the test box):
+    contiguous candidate shards + the argmax rule == the single-engine answer, bitwise."""
+    from spearmint_amd.engine import MultiEngine
+    comp, cand, vals, hypers = synthetic_problem(200, 3001, 5, 4, 61)
+    one = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    me = MultiEngine([0, 0, 0])
+    try:
+        many = me.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        assert many[0] == one[0] and many[1] == one[1]
+        assert np.array_equal(many[2], one[2]) and np.array_equal(many[3], one[3])
+        lp = me.gp_logprob()
+        assert lp.shape == (4,)
+    finally:
+        me.close()
+
+
+def test_chooser_with_ndev(golden_dir, tmp_path):
+    from spearmint_amd.chooser import GPEIChooser
+    g = _g(golden_dir, "branin_c1.npz")
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=10,ndev=1,device=0")
+    npr.seed(int(g["seed"]))
+    assert ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"]) == int(g["job"])
