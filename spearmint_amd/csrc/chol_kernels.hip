@@ -9,9 +9,11 @@
 // Matrices: [nh][Np][Np] row-major, Np a multiple of 128, block size NB = 64.
 // Left-looking, one block column k at a time (two launches per k):
 //   k_chol_diag   1 workgroup / draw : S = K_kk - L_k,:k L_k,:k^T (MFMA, panels
-//                 staged in LDS), in-LDS Cholesky of the 64x64 block by one
-//                 wavefront (column scale + rank-1 update, the pivot column
-//                 broadcast lane-to-lane with v_readlane), then its inverse.
+//                 staged in LDS); the 64x64 block is factored with 16x16
+//                 sub-blocks: each diagonal sub-block by one wavefront with its
+//                 rows in registers and the pivot column broadcast lane-to-lane
+//                 (v_readlane), sub-panel and trailing updates by MFMA; then the
+//                 inverse of the block by block forward substitution (MFMA).
 //   k_chol_panel  1 workgroup / (row block > k, draw):
 //                 L_rk = (K_rk - L_r,:k L_k,:k^T) L_kk^-T          (MFMA)
 // k_trinv: W = L^-1 by block columns (one launch), stored transposed
@@ -63,9 +65,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
                                                    int* __restrict__ info, int Np, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* P = smem;                  // [64][LDP]
-    double* S = P + NB * LDP;          // [64][LDS_S]
-    double* X = S + NB * LDS_S;        // [64][LDS_S]
+    double* P = smem;                  // [64][LDP] staging tile of the row panel
+    double* S = P + NB * LDP;          // [64][LDP] the diagonal block, factored in place
+    double* XT = S + NB * LDP;         // [64][LDP] (L_kk^-1)^T
+    double* T16 = XT + NB * LDP;       // [4][16][18] inverses of the 16x16 diagonal sub-blocks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int h = blockIdx.x;
@@ -89,72 +92,137 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S[(16 * wave + g + 4 * r) * LDS_S + 16 * nt + li] = acc[nt][r];
+        for (int r = 0; r < 4; ++r) S[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
     __syncthreads();
 
-    if (wave == 0) {
-        // --- unblocked Cholesky of S: lane i keeps row i in registers (fully unrolled,
-        // static register indices); column j is scaled by 1/sqrt(pivot) and the trailing
-        // update a[i][kc] -= l_ij * l_kc,j takes l_kc,j from lane kc with v_readlane.
-        // Entries above the diagonal are updated too (no predicate) but never read.
-        // (A ds_bpermute/__shfl variant and sched_group_barrier pipelining were tried:
-        // hipcc then demotes the row array to scratch; this form measured fastest.)
-        const int i = lane;
-        double a[NB];
+    // ---- blocked Cholesky of the 64x64 block, 16x16 sub-blocks ----------------------------
+    // per sub-block column b: (a) one wavefront factors the 16x16 diagonal sub-block with the
+    // row of lane i in registers (pivot column broadcast lane-to-lane by v_readlane) and
+    // inverts it; (b) the sub-panel below is multiplied by that inverse (MFMA); (c) the
+    // trailing sub-blocks get their rank-16 update (MFMA).
+    int bad = 0;
+    for (int b = 0; b < 4; ++b) {
+        const int b0 = 16 * b;
+        double* Tb = T16 + b * 16 * 18;
+        if (wave == 0) {
+            const int i = li;   // the four 16-lane groups hold identical copies
+            double a[16], rinvs[16];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = S[i * LDS_S + c];
-        int bad = 0;
+            for (int c = 0; c < 16; ++c) a[c] = S[(b0 + i) * LDP + b0 + c];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            double d = readlane_f64(a[j], j);
-            if (!(d > 0.0)) {  // also catches NaN, like LAPACK dpotrf's (ajj <= 0 || isnan)
-                if (!bad) bad = (int)kb0 + j + 1;
-                d = 1.0;
+            for (int j = 0; j < 16; ++j) {
+                double d = readlane_f64(a[j], j);
+                if (!(d > 0.0)) {  // also catches NaN, like LAPACK dpotrf's (ajj <= 0 || isnan)
+                    if (!bad) bad = (int)kb0 + b0 + j + 1;
+                    d = 1.0;
+                }
+                const double sd = sqrt(d);
+                const double rinv = 1.0 / sd;
+                rinvs[j] = rinv;
+                double lij = 0.0;
+                if (i > j) lij = a[j] * rinv;
+                else if (i == j) lij = sd;
+                a[j] = lij;
+#pragma unroll
+                for (int kc = j + 1; kc < 16; ++kc) a[kc] -= lij * readlane_f64(lij, kc);
             }
-            const double sd = sqrt(d);
-            const double rinv = 1.0 / sd;
-            double lij = 0.0;
-            if (i > j) lij = a[j] * rinv;
-            else if (i == j) lij = sd;
-            a[j] = lij;
+            // inverse of the 16x16 factor: lane c builds column c by forward substitution
+            double x[16];
 #pragma unroll
-            for (int kc = j + 1; kc < NB; ++kc) {
-                const double lk = readlane_f64(lij, kc);
-                a[kc] -= lij * lk;
+            for (int r = 0; r < 16; ++r) {
+                double t = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+                for (int p = 0; p < r; ++p) t -= readlane_f64(a[p], r) * x[p];
+                x[r] = (r >= i) ? t * rinvs[r] : 0.0;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    S[(b0 + i) * LDP + b0 + c] = (c <= i) ? a[c] : 0.0;
+                    Tb[c * 18 + i] = x[c];                      // Linv16[r = c][col = i]
+                    XT[(b0 + i) * LDP + b0 + c] = x[c];         // XT[col][row] = X[row][col]
+                }
             }
         }
-        if (bad && lane == 0) {
-            if (info[h] == 0) info[h] = bad;
+        __syncthreads();
+        // (b) sub-panel: rows of tile ti = b+1+wave, P <- P Linv16^T
+        {
+            const int ti = b + 1 + wave;
+            if (ti < 4) {
+                d4 c4 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const double av = S[(16 * ti + li) * LDP + b0 + 4 * ks + g];
+                    const double bv = Tb[li * 18 + 4 * ks + g];
+                    c4 = MFMA_F64(av, bv, c4);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + b0 + li] = c4[r];
+            }
         }
+        __syncthreads();
+        // (c) trailing update of the sub-blocks (ti, tj), b < tj <= ti
+        {
+            int idx = 0;
+            for (int ti = b + 1; ti < 4; ++ti)
+                for (int tj = b + 1; tj <= ti; ++tj, ++idx) {
+                    if ((idx & 3) != wave) continue;
+                    d4 c4;
 #pragma unroll
-        for (int c = 0; c < NB; ++c) S[i * LDS_S + c] = (c <= i) ? a[c] : 0.0;
-        // --- X = L_kk^-1 by forward substitution: lane c keeps column c of X in registers,
-        // L[r][p] is a wave-uniform (broadcast) LDS read that does not depend on X.
-        const int c = lane;
-        double x[NB];
+                    for (int r = 0; r < 4; ++r) c4[r] = S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) {
-            double acc = (r == c) ? 1.0 : 0.0;
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const double av = -S[(16 * ti + li) * LDP + b0 + 4 * ks + g];
+                        const double bv = S[(16 * tj + li) * LDP + b0 + 4 * ks + g];
+                        c4 = MFMA_F64(av, bv, c4);
+                    }
 #pragma unroll
-            for (int p = 0; p < r; ++p) acc -= S[r * LDS_S + p] * x[p];
-            x[r] = (r >= c) ? acc / S[r * LDS_S + r] : 0.0;
+                    for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li] = c4[r];
+                }
         }
+        __syncthreads();
+    }
+    if (wave == 0 && lane == 0 && bad) {
+        if (info[h] == 0) info[h] = bad;
+    }
+
+    // ---- X = L_kk^-1 by block forward substitution, wave j owns sub-block column j -----------
+    //   X_jj = Linv16_j ;  X_ij = -Linv16_i * sum_{p=j}^{i-1} L_ip X_pj          (i > j)
+    // XT holds X transposed so that X_pj is read in the MFMA B-operand pattern; the
+    // accumulator of the first product is itself in B-operand layout for the second.
+    {
+        const int j = wave;
+        for (int i = j + 1; i < 4; ++i) {
+            d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int pb = j; pb < i; ++pb) {
 #pragma unroll
-        for (int r = 0; r < NB; ++r) X[r * LDS_S + c] = x[r];
+                for (int ks = 0; ks < 4; ++ks) {
+                    const double av = S[(16 * i + li) * LDP + 16 * pb + 4 * ks + g];
+                    const double bv = XT[(16 * j + li) * LDP + 16 * pb + 4 * ks + g];
+                    t4 = MFMA_F64(av, bv, t4);
+                }
+            }
+            d4 o4 = (d4){0.0, 0.0, 0.0, 0.0};
+            const double* Ti = T16 + i * 16 * 18;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) o4 = MFMA_F64(-Ti[li * 18 + 4 * ks + g], t4[ks], o4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
+        }
     }
     __syncthreads();
     // write L_kk (upper part zero) and its inverse
     double* Dk = Dinv + ((size_t)h * nblk + k) * NB * NB;
     for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
         const int row = idx >> 6, col = idx & 63;
-        Lh[(kb0 + row) * Np + kb0 + col] = (col <= row) ? S[row * LDS_S + col] : 0.0;
-        Dk[idx] = X[row * LDS_S + col];
+        Lh[(kb0 + row) * Np + kb0 + col] = (col <= row) ? S[row * LDP + col] : 0.0;
+        Dk[idx] = (col <= row) ? XT[col * LDP + row] : 0.0;
     }
 }
 
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh)
 {
-    const size_t lds = (size_t)(NB * LDP + 2 * NB * LDS_S) * sizeof(double);   // 100 KB > the 64 KB default
+    const size_t lds = (size_t)(3 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 108 KB > the 64 KB default
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k);
