@@ -44,6 +44,25 @@ __device__ __forceinline__ void tile_to_lds(const double* __restrict__ g, size_t
     }
 }
 
+// the same copy split in two so the global loads of step p+1 fly while step p computes
+struct TileRegs { d2 v[8]; };
+__device__ __forceinline__ void tile_load(const double* __restrict__ g, size_t ld, TileRegs& t)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = threadIdx.x + 256 * q;
+        t.v[q] = *reinterpret_cast<const d2*>(g + (size_t)(idx >> 5) * ld + 2 * (idx & 31));
+    }
+}
+__device__ __forceinline__ void tile_store(const TileRegs& t, double* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = threadIdx.x + 256 * q;
+        *reinterpret_cast<d2*>(lds + (idx >> 5) * LDP + 2 * (idx & 31)) = t.v[q];
+    }
+}
+
 // acc[nt] (+)= sign * A_lds[16w+li][:] . B_lds[16nt+li][:]^T over the 64-deep tile
 __device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B_lds, d4 acc[4],
                                             int wave, int g, int li, bool negate)
@@ -65,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
                                                    int* __restrict__ info, int Np, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* P = smem;                  // [64][LDP] staging tile of the row panel
-    double* S = P + NB * LDP;          // [64][LDP] the diagonal block, factored in place
+    double* P = smem;                  // [2][64][LDP] staging tiles of the row panel (double-buffered)
+    double* S = P + 2 * NB * LDP;      // [64][LDP] the diagonal block, factored in place
     double* XT = S + NB * LDP;         // [64][LDP] (L_kk^-1)^T
     double* T16 = XT + NB * LDP;       // [4][16][18] inverses of the 16x16 diagonal sub-blocks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -83,11 +102,18 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             acc[nt][r] = Lh[(kb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
-    for (int p = 0; p < k; ++p) {
-        __syncthreads();
-        tile_to_lds(Lh + kb0 * Np + (size_t)p * NB, Np, P);
-        __syncthreads();
-        mma_tile_64(P, P, acc, wave, g, li, true);
+    if (k > 0) {
+        // one barrier per step: step p's tile is written to buffer p&1 while nobody can still be
+        // reading it (every wave finished step p-2's MFMAs before the barrier of step p-1)
+        TileRegs tr;
+        tile_load(Lh + kb0 * Np, Np, tr);
+        for (int p = 0; p < k; ++p) {
+            double* Pc = P + (p & 1) * NB * LDP;
+            tile_store(tr, Pc);
+            __syncthreads();
+            if (p + 1 < k) tile_load(Lh + kb0 * Np + (size_t)(p + 1) * NB, Np, tr);
+            mma_tile_64(Pc, Pc, acc, wave, g, li, true);
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -222,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
 
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh)
 {
-    const size_t lds = (size_t)(3 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 108 KB > the 64 KB default
+    const size_t lds = (size_t)(4 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 144 KB > the 64 KB default
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k);
@@ -233,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
                                                     const double* __restrict__ Dinv, int Np, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* A = smem;             // [64][LDP]
-    double* B = smem + NB * LDP;  // [64][LDP]
+    double* A = smem;                  // [2][64][LDP]
+    double* B = smem + 2 * NB * LDP;   // [2][64][LDP]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
@@ -249,12 +275,22 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             acc[nt][r] = Lh[(rb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
-    for (int p = 0; p < k; ++p) {
-        __syncthreads();
-        tile_to_lds(Lh + rb0 * Np + (size_t)p * NB, Np, A);
-        tile_to_lds(Lh + kb0 * Np + (size_t)p * NB, Np, B);
-        __syncthreads();
-        mma_tile_64(A, B, acc, wave, g, li, true);
+    if (k > 0) {
+        TileRegs ta, tb;
+        tile_load(Lh + rb0 * Np, Np, ta);
+        tile_load(Lh + kb0 * Np, Np, tb);
+        for (int p = 0; p < k; ++p) {
+            double* Ac = A + (p & 1) * NB * LDP;
+            double* Bc = B + (p & 1) * NB * LDP;
+            tile_store(ta, Ac);
+            tile_store(tb, Bc);
+            __syncthreads();
+            if (p + 1 < k) {
+                tile_load(Lh + rb0 * Np + (size_t)(p + 1) * NB, Np, ta);
+                tile_load(Lh + kb0 * Np + (size_t)(p + 1) * NB, Np, tb);
+            }
+            mma_tile_64(Ac, Bc, acc, wave, g, li, true);
+        }
     }
     __syncthreads();
     // L_rk = S L_kk^-T :  out[i][n] = sum_q S[i][q] Dinv[n][q]
@@ -278,7 +314,7 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 {
     const int nblk = Np / NB;
     if (nblk - k - 1 <= 0) return;
-    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);                // 67.6 KB
+    const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);                // 135 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_panel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k - 1, nh), dim3(256), lds, s, L, Dinv, Np, k);
@@ -298,8 +334,8 @@ __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
                                                double* __restrict__ WT, int Np)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* A = smem;
-    double* B = smem + NB * LDP;
+    double* A = smem;                  // [2][64][LDP]
+    double* B = smem + 2 * NB * LDP;   // [2][64][LDP]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
@@ -321,12 +357,23 @@ __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
         d4 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int p = jb; p < ib; ++p) {
-            __syncthreads();  // also orders the previous iteration's WT stores before these loads
-            tile_to_lds(Wh + j0 * Np + (size_t)p * NB, Np, A);
-            tile_to_lds(Lh + i0 * Np + (size_t)p * NB, Np, B);
-            __syncthreads();
-            mma_tile_64(A, B, acc, wave, g, li, false);
+        __syncthreads();  // orders the previous iteration's WT stores (and LDS reads) before what follows
+        {
+            TileRegs ta, tb;
+            tile_load(Wh + j0 * Np + (size_t)jb * NB, Np, ta);
+            tile_load(Lh + i0 * Np + (size_t)jb * NB, Np, tb);
+            for (int p = jb; p < ib; ++p) {
+                double* Ac = A + ((p - jb) & 1) * NB * LDP;
+                double* Bc = B + ((p - jb) & 1) * NB * LDP;
+                tile_store(ta, Ac);
+                tile_store(tb, Bc);
+                __syncthreads();
+                if (p + 1 < ib) {
+                    tile_load(Wh + j0 * Np + (size_t)(p + 1) * NB, Np, ta);
+                    tile_load(Lh + i0 * Np + (size_t)(p + 1) * NB, Np, tb);
+                }
+                mma_tile_64(Ac, Bc, acc, wave, g, li, false);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -349,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
 
 void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh)
 {
-    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);
+    const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trinv),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_trinv, dim3(Np / NB, nh), dim3(256), lds, s, L, Dinv, WT, Np);
