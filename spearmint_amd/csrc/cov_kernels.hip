@@ -55,8 +55,51 @@ void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad,
                        factor, xs, sumsq);
 }
 
+// sqrt(x) for x >= 0 (x = 0 allowed), ~1 ulp: v_rsq_f64 seed + two coupled Newton steps.
+// Leaner than the library sqrt (no denormal rescaling / special-case selects): this epilogue
+// runs once per covariance entry, 4e8 times per draw at C3.
+__device__ __forceinline__ double sqrt_nonneg(double x)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0;
+    double hh = 0.5 * y0;
+    double r = fma(-hh, g, 0.5);
+    g = fma(g, r, g);
+    hh = fma(hh, r, hh);
+    const double d = fma(-g, g, x);
+    g = fma(d, hh, g);
+    return (x > 0.0) ? g : x;   // x == 0 -> 0 (rsq(0) = inf), NaN propagates
+}
+
+// exp(-t) for t >= 0, ~1 ulp: n = rint(-t log2 e), Cody-Waite reduction with a two-part ln 2,
+// degree-13 Taylor polynomial on |f| <= ln2/2, scale by 2^n (v_ldexp_f64).  t > 745 -> 0.
+__device__ __forceinline__ double exp_neg(double t)
+{
+    const double x = -t;
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double f = fma(n, -6.93147180369123816490e-01, x);   // ln2_hi
+    f = fma(n, -1.90821492927058770002e-10, f);           // ln2_lo
+    double p = 1.6059043836821613e-10;                    // 1/13!
+    p = fma(p, f, 2.08767569878681e-09);                  // 1/12!
+    p = fma(p, f, 2.505210838544172e-08);                 // 1/11!
+    p = fma(p, f, 2.755731922398589e-07);                 // 1/10!
+    p = fma(p, f, 2.7557319223985893e-06);                // 1/9!
+    p = fma(p, f, 2.48015873015873e-05);                  // 1/8!
+    p = fma(p, f, 1.984126984126984e-04);                 // 1/7!
+    p = fma(p, f, 1.3888888888888889e-03);                // 1/6!
+    p = fma(p, f, 8.333333333333333e-03);                 // 1/5!
+    p = fma(p, f, 4.1666666666666664e-02);                // 1/4!
+    p = fma(p, f, 1.6666666666666666e-01);                // 1/3!
+    p = fma(p, f, 0.5);
+    p = fma(p, f, 1.0);
+    p = fma(p, f, 1.0);
+    const double r = __builtin_ldexp(p, (int)n);
+    return (t < 745.2) ? r : ((t != t) ? t : 0.0);
+}
+
 // Matern-5/2 correlation from the Gram term and the two squared norms, in the
-// reference's operation order (no FMA contraction so each step rounds as numpy's).
+// reference's operation order (the polynomial and the clamp round as numpy's do; sqrt and
+// exp are ~1 ulp device implementations).
 __device__ __forceinline__ double matern52_corr(double g, double s1, double s2)
 {
 #pragma clang fp contract(off)
@@ -64,9 +107,9 @@ __device__ __forceinline__ double matern52_corr(double g, double s1, double s2)
     const double nt = -t;
     double r2 = (nt < 0.0) ? 0.0 : nt;  // np.maximum(., 0): NaN propagates (fmax would drop it)
     r2 = fabs(r2);
-    const double r = sqrt(r2);
+    const double r = sqrt_nonneg(r2);
     const double poly = (1.0 + SQRT5 * r) + (5.0 / 3.0) * r2;
-    return poly * exp(-SQRT5 * r);
+    return poly * exp_neg(SQRT5 * r);
 }
 
 // ---------------------------------------------------------------------------
