@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kstar-budget-mb", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="0 = library default")
+    ap.add_argument("--gemm-waves", type=int, default=0, help="predict GEMM variant: 4 or 8 waves per workgroup")
     ap.add_argument("--host-inclusive", action="store_true",
                     help="also time the one-shot host-buffer entry point (PCIe H2D/D2H included)")
     args = ap.parse_args()
@@ -158,6 +159,8 @@ def main():
         eng.set_option("kstar_budget_bytes", args.kstar_budget_mb << 20)
     if args.streams:
         eng.set_option("streams", args.streams)
+    if args.gemm_waves:
+        eng.set_option("gemm_waves", args.gemm_waves)
 
     def sync():
         if world > 1:

@@ -15,10 +15,13 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, double seed)
     for (int i = 0; i < NACC; ++i) acc[i] = (d4){seed, seed, seed, seed};
     for (int i = 0; i < 8; ++i) v[i] = seed + i;
     double a = seed + threadIdx.x * 1e-9, b = seed * 0.5;
+    double av[4], bv[4];   // MODE 4: distinct A/B operand registers in the 4x4 pattern of a GEMM wave tile
+    for (int i = 0; i < 4; ++i) { av[i] = a + i * 1e-7; bv[i] = b - i * 1e-7; }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
             if (MODE == 3) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            else if (MODE == 4) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(av[i & 3]), "v"(bv[(i >> 2) & 3]));
             else if (MODE != 1) acc[i] = MFMA(a, b, acc[i]);
             if (MODE == 1 || MODE == 2) {
 #pragma unroll
@@ -61,6 +64,7 @@ int main()
         run<16, 0>("mfma only, 16 acc", b, d, 1250);
         run<8, 3>("mfma VGPR acc (asm), 8 acc", b, d, 2500);
         run<16, 3>("mfma VGPR acc (asm), 16 acc", b, d, 1250);
+        run<16, 4>("mfma VGPR acc, 4x4 distinct A/B", b, d, 1250);
         run<8, 1>("valu fma only", b, d, 2500);
         run<8, 2>("mfma + 8 fma interleaved", b, d, 2500);
     }

@@ -66,6 +66,7 @@ void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, con
 void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
                          double* part_ss, double* part_bg, int Np, int Mc, int nh,
                          const double* gammaS = nullptr, int S = 0, double* part_bgS = nullptr);
+void set_predict_gemm_waves(int nw);
 void launch_ei_finalize_fant(hipStream_t s, const double* part_ss, const double* part_bgS,
                              const double* htab, const double* bests, const double* time_m,
                              double* ei_draw, int nrb, int Mc, int nh, int S, int64_t c0, int64_t M,

@@ -28,7 +28,13 @@
 // Grid: 1-D, XCD-aware (see the block -> tile map below), heaviest row blocks first.
 // part_ss / part_bg: [nrb][nh][Mc]
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_predict_gemm(
+// NW = waves per workgroup: 4 (wave tile 64x64) or 8 (wave tile 32x64).
+// STG = how the operand tiles reach LDS: 0 registers + ds_write (prefetch distance one tile),
+//       1 LDS-DMA (global_load_lds, no staging registers, no ds_write).
+// ABL > 0: timing-only ablations for performance analysis (wrong results): 1 = no in-loop
+// global loads / LDS stores, 2 = also no barriers, 3 = also operand fragments read once.
+template <int NW, int STG, int ABL>
+__global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     const double* __restrict__ WT, const double* __restrict__ Kst,
     const double* __restrict__ gamma, double* __restrict__ part_ss,
     double* __restrict__ part_bg, int Np, int Mc, int nh, int ncb, int nrb,
@@ -43,6 +49,9 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
+    constexpr int MT = 16 / NW;         // 16-row MFMA tiles per wave (rows per wave = 16 MT)
+    constexpr int NQ = 16 / NW;         // staging: tile rows (16-byte loads) per thread per operand tile
+    constexpr int WROWS = 16 * MT;
 
     // Block -> tile map, XCD-aware.  Workgroup b is dispatched to XCD b % 8 (each XCD
     // has a private 4 MiB L2).  All row blocks ib of one candidate tile (h, cb) read the
@@ -66,54 +75,78 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(
     const int nk = (ib + 1) * (BM / BK);
 
     // global->LDS staging map: 4 x 16 B per thread per operand tile (16 rows x 128 doubles)
-    const int lrow = tid >> 6;        // + 4 q
+    const int lrow = tid >> 6;        // + NW q
     const int lcol = (tid & 63) * 2;  // doubles
-    d2 ra[4], rb[4];
-
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = lrow + 4 * q;
-        ra[q] = *reinterpret_cast<const d2*>(Ag + (size_t)row * Np + lcol);
-        rb[q] = *reinterpret_cast<const d2*>(Bg + (size_t)row * Mc + lcol);
+    d2 ra[NQ], rb[NQ];
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    // LDS-DMA: one instruction moves one 1 KiB tile row (64 lanes x 16 B) straight into LDS at a
+    // wave-uniform base (+ lane * 16 B); rows stay padded to LDT because every row is its own
+    // instruction.  Wave w moves rows w, w + NW, ... of both operand tiles.
+#define SPX_DMA_TILE(KT_, BUF_)                                                                            \
+    {                                                                                                      \
+        const size_t j0_ = (size_t)(KT_) * BK;                                                             \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
+            const int row = wave + NW * q;                                                                 \
+            __builtin_amdgcn_global_load_lds(Ag + (j0_ + row) * Np + 2 * lane,                             \
+                                             (lds_void_t*)(As + (BUF_) * BK * LDT + row * LDT), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds(Bg + (j0_ + row) * Mc + 2 * lane,                             \
+                                             (lds_void_t*)(Bs + (BUF_) * BK * LDT + row * LDT), 16, 0, 0); \
+        }                                                                                                  \
     }
+    if (STG == 1) {
+        SPX_DMA_TILE(0, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = lrow + 4 * q;
-        *reinterpret_cast<d2*>(As + row * LDT + lcol) = ra[q];
-        *reinterpret_cast<d2*>(Bs + row * LDT + lcol) = rb[q];
+        for (int q = 0; q < NQ; ++q) {
+            const int row = lrow + NW * q;
+            ra[q] = *reinterpret_cast<const d2*>(Ag + (size_t)row * Np + lcol);
+            rb[q] = *reinterpret_cast<const d2*>(Bg + (size_t)row * Mc + lcol);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int row = lrow + NW * q;
+            *reinterpret_cast<d2*>(As + row * LDT + lcol) = ra[q];
+            *reinterpret_cast<d2*>(Bs + row * LDT + lcol) = rb[q];
+        }
     }
     __syncthreads();
 
-    d4 acc[4][4];
+    d4 acc[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
 
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
+        if (STG == 1 && ABL == 0 && kt + 1 < nk) SPX_DMA_TILE(kt + 1, cur ^ 1)
+        const bool more = (STG == 0) && (ABL == 0) && (kt + 1 < nk);
         if (more) {
             const size_t j0 = (size_t)(kt + 1) * BK;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const size_t row = j0 + lrow + 4 * q;
+            for (int q = 0; q < NQ; ++q) {
+                const size_t row = j0 + lrow + NW * q;
                 ra[q] = *reinterpret_cast<const d2*>(Ag + row * Np + lcol);
                 rb[q] = *reinterpret_cast<const d2*>(Bg + row * Mc + lcol);
             }
         }
-        const double* Ac = As + cur * BK * LDT + 64 * wm + li;
+        const double* Ac = As + cur * BK * LDT + WROWS * wm + li;
         const double* Bc = Bs + cur * BK * LDT + 64 * wn + li;
 #pragma unroll
         for (int k0 = 0; k0 < BK; k0 += 4) {
-            double a[4], b[4];
+            double a[MT], b[4];
+            const int kk = (ABL == 3) ? 0 : k0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = Ac[(k0 + g) * LDT + 16 * t];
-                b[t] = Bc[(k0 + g) * LDT + 16 * t];
+            for (int t = 0; t < 4; ++t) b[t] = Bc[(kk + g) * LDT + 16 * t];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[t] = Ac[(kk + g) * LDT + 16 * t];
+            if (ABL == 3) {  // keep the values opaque so the loads are hoisted but the MFMAs stay
+#pragma unroll
+                for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(b[t]));
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA_F64(a[mt], b[nt], acc[mt][nt]);
         }
@@ -121,31 +154,33 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(
             double* An = As + (cur ^ 1) * BK * LDT;
             double* Bn = Bs + (cur ^ 1) * BK * LDT;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = lrow + 4 * q;
+            for (int q = 0; q < NQ; ++q) {
+                const int row = lrow + NW * q;
                 *reinterpret_cast<d2*>(An + row * LDT + lcol) = ra[q];
                 *reinterpret_cast<d2*>(Bn + row * LDT + lcol) = rb[q];
             }
         }
-        __syncthreads();
-        cur ^= 1;
+        if (STG == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA rows have landed
+        if (ABL < 2) __syncthreads();
+        if (ABL == 0) cur ^= 1;
     }
+#undef SPX_DMA_TILE
 
     // ---- epilogue: column sums of C^2 and C*gamma over this block's 128 rows ----
-    // accumulator layout: acc[mt][nt][r] = C[64 wm + 16 mt + g + 4 r][64 wn + 16 nt + li]
-    const double* gh = gamma + (size_t)h * Np + (size_t)ib * BM + 64 * wm;
-    double gam[4][4];
+    // accumulator layout: acc[mt][nt][r] = C[WROWS wm + 16 mt + g + 4 r][64 wn + 16 nt + li]
+    const double* gh = gamma + (size_t)h * Np + (size_t)ib * BM + WROWS * wm;
+    double gam[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) gam[mt][r] = gh[16 * mt + g + 4 * r];
 
-    double* red = smem;  // [2 (wm)][128][2]; safe: every wave passed the last barrier of the K loop
+    double* red = smem;  // [NW/2 (wm)][128][2]; safe: every wave passed the last barrier of the K loop
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         double ss = 0.0, bg = 0.0;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double v = acc[mt][nt][r];
@@ -164,8 +199,12 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(
     }
     __syncthreads();
     if (tid < BN) {
-        const double ss = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
-        const double bg = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+        double ss = red[tid * 2 + 0], bg = red[tid * 2 + 1];
+#pragma unroll
+        for (int w = 1; w < NW / 2; ++w) {          // row groups in order
+            ss += red[(w * BN + tid) * 2 + 0];
+            bg += red[(w * BN + tid) * 2 + 1];
+        }
         const size_t o = ((size_t)ib * nh + h) * Mc + (size_t)cb * BN + tid;
         part_ss[o] = ss;
         part_bg[o] = bg;
@@ -175,21 +214,21 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(
     // against S right-hand sides, func_m[c][s] = sum_i beta[i][c] Gamma_s[i] + mean.  Each wave
     // reduces its 64 rows; the two row halves (wm) are written separately and summed, in
     // fixed order, by k_ei_finalize_fant.
-    if (S > 0) {
+    if (NW == 4 && S > 0) {
         const double* gS = gammaS + (size_t)h * S * Np + (size_t)ib * BM + 64 * wm;
         double* outS = part_bgS + ((((size_t)ib * 2 + wm) * nh + h) * S) * Mc + (size_t)cb * BN + 64 * wn;
         for (int sidx = 0; sidx < S; ++sidx) {
             const double* gs = gS + (size_t)sidx * Np;
-            double gv[4][4];
+            double gv[MT][4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[mt][r] = gs[16 * mt + g + 4 * r];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 double bg = 0.0;
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bg = fma(acc[mt][nt][r], gv[mt][r], bg);
                 bg += __shfl_xor(bg, 16);
@@ -200,18 +239,45 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(
     }
 }
 
+// variant selector (process-wide, spx_set_option "gemm_variant"): 0 = default,
+// 4 / 8 = waves per workgroup with register staging, 14 / 18 = same with LDS-DMA staging,
+// 41..43 = timing-only ablations of the 4-wave register-staged kernel.
+static int g_gemm_variant = 0;
+void set_predict_gemm_waves(int v) { g_gemm_variant = v; }
+
+template <int NW, int STG, int ABL>
+static void launch_gemm_variant(hipStream_t s, int grid, size_t lds, const double* WT, const double* Kst,
+                                const double* gamma, double* part_ss, double* part_bg, int Np, int Mc, int nh,
+                                int ncb, int nrb, const double* gammaS, int S, double* part_bgS)
+{
+    // attribute set per launch (not cached): it is per device, and one process may drive several GPUs
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm<NW, STG, ABL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_predict_gemm<NW, STG, ABL>), dim3(grid), dim3(64 * NW), lds, s, WT, Kst, gamma, part_ss,
+                       part_bg, Np, Mc, nh, ncb, nrb, gammaS, S, part_bgS);
+}
+
 void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
                          double* part_ss, double* part_bg, int Np, int Mc, int nh,
                          const double* gammaS, int S, double* part_bgS)
 {
     const int ncb = Mc / BN, nrb = Np / BM;
     const size_t lds = (size_t)(4 * BK * LDT) * sizeof(double);
-    // per launch (not cached): the attribute is per device, and one process may drive several GPUs
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int grid = 8 * ((ncb + 7) / 8) * nrb * nh;
-    hipLaunchKernelGGL(k_predict_gemm, dim3(grid), dim3(256), lds, s, WT, Kst, gamma,
-                       part_ss, part_bg, Np, Mc, nh, ncb, nrb, gammaS, S, part_bgS);
+#define SPX_GO(NW_, STG_, ABL_)                                                                               \
+    launch_gemm_variant<NW_, STG_, ABL_>(s, grid, lds, WT, Kst, gamma, part_ss, part_bg, Np, Mc, nh, ncb, nrb, \
+                                         gammaS, S, part_bgS)
+    const int v = (S > 0) ? 4 : g_gemm_variant;   // the fantasy epilogue exists in the 4-wave kernel
+    switch (v) {
+        case 8:  SPX_GO(8, 0, 0); break;
+        case 14: SPX_GO(4, 1, 0); break;
+        case 18: SPX_GO(8, 1, 0); break;
+        case 41: SPX_GO(4, 0, 1); break;
+        case 42: SPX_GO(4, 0, 2); break;
+        case 43: SPX_GO(4, 0, 3); break;
+        default: SPX_GO(4, 0, 0); break;
+    }
+#undef SPX_GO
 }
 
 // ---------------------------------------------------------------------------

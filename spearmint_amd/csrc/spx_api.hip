@@ -212,6 +212,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->kst_budget = value > 0 ? value : (512ll << 20);
         return SPX_OK;
     }
+    if (!strcmp(name, "gemm_waves")) {   // 4 (default) or 8 waves per predict-GEMM workgroup (process-wide)
+        set_predict_gemm_waves((int)value);
+        return SPX_OK;
+    }
     if (!strcmp(name, "streams")) {  // 1 = everything on one stream (default), 2 = alternate EI work items
         h->nstreams = value == 2 ? 2 : 1;
         return SPX_OK;
