@@ -77,8 +77,63 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     // global->LDS staging map: 4 x 16 B per thread per operand tile (16 rows x 128 doubles)
     const int lrow = tid >> 6;        // + NW q
     const int lcol = (tid & 63) * 2;  // doubles
-    d2 ra[NQ], rb[NQ];
     typedef __attribute__((address_space(3))) void lds_void_t;
+    d4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  if constexpr (STG == 2) {
+    // ---- LDS-DMA staging, three LDS buffers of 8 rows, two tiles in flight --------------------
+    // Step kt issues the DMA of tile kt+2, computes tile kt, then waits only until tile kt+1 has
+    // landed (counted vmcnt) and passes a raw s_barrier: a __syncthreads() would drain the
+    // in-flight DMA with vmcnt(0).  Buffer (kt+2)%3 was last read in step kt-1, which every
+    // wave finished before the barrier that ended it.
+    constexpr int BD = 8, RQ = BD / NW;
+    static_assert(NW == 4, "DMA pipeline is written for 4 waves");
+    double* A3 = smem;                    // [3][BD][LDT]
+    double* B3 = smem + 3 * BD * LDT;     // [3][BD][LDT]
+    const int nk2 = (ib + 1) * (BM / BD);
+#define SPX_DMA3(KT_, BUF_)                                                                           \
+    {                                                                                                 \
+        const size_t j0_ = (size_t)(KT_) * BD;                                                        \
+        _Pragma("unroll") for (int q = 0; q < RQ; ++q) {                                              \
+            const int row = wave + NW * q;                                                            \
+            __builtin_amdgcn_global_load_lds(Ag + (j0_ + row) * Np + 2 * lane,                        \
+                                             (lds_void_t*)(A3 + (BUF_) * BD * LDT + row * LDT), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds(Bg + (j0_ + row) * Mc + 2 * lane,                        \
+                                             (lds_void_t*)(B3 + (BUF_) * BD * LDT + row * LDT), 16, 0, 0); \
+        }                                                                                             \
+    }
+    SPX_DMA3(0, 0)
+    SPX_DMA3(1, 1)                        // nk2 >= 16
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");     // tile 0 landed (2 RQ = 4 younger DMAs may fly)
+    int b0 = 0, b1 = 1, b2 = 2;           // buffers of tiles kt, kt+1, kt+2
+    for (int kt = 0; kt < nk2; ++kt) {
+        const bool more = (kt + 2 < nk2);
+        if (more) SPX_DMA3(kt + 2, b2)
+        const double* Ac = A3 + b0 * BD * LDT + WROWS * wm + li;
+        const double* Bc = B3 + b0 * BD * LDT + 64 * wn + li;
+#pragma unroll
+        for (int k0 = 0; k0 < BD; k0 += 4) {
+            double a[MT], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = Bc[(k0 + g) * LDT + 16 * t];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[t] = Ac[(k0 + g) * LDT + 16 * t];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA_F64(a[mt], b[nt], acc[mt][nt]);
+        }
+        if (more) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const int t = b0; b0 = b1; b1 = b2; b2 = t;
+    }
+#undef SPX_DMA3
+  } else {
+    d2 ra[NQ], rb[NQ];
     // LDS-DMA: one instruction moves one 1 KiB tile row (64 lanes x 16 B) straight into LDS at a
     // wave-uniform base (+ lane * 16 B); rows stay padded to LDT because every row is its own
     // instruction.  Wave w moves rows w, w + NW, ... of both operand tiles.
@@ -111,12 +166,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
         }
     }
     __syncthreads();
-
-    d4 acc[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
 
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -166,6 +215,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     }
 #undef SPX_DMA_TILE
 
+  }
     // ---- epilogue: column sums of C^2 and C*gamma over this block's 128 rows ----
     // accumulator layout: acc[mt][nt][r] = C[WROWS wm + 16 mt + g + 4 r][64 wn + 16 nt + li]
     const double* gh = gamma + (size_t)h * Np + (size_t)ib * BM + WROWS * wm;
@@ -239,8 +289,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     }
 }
 
-// variant selector (process-wide, spx_set_option "gemm_variant"): 0 = default,
+// variant selector (process-wide, spx_set_option "gemm_waves"): 0 = default (= 14),
 // 4 / 8 = waves per workgroup with register staging, 14 / 18 = same with LDS-DMA staging,
+// 24 = LDS-DMA with three 8-row buffers and two tiles in flight (counted vmcnt + raw s_barrier),
 // 41..43 = timing-only ablations of the 4-wave register-staged kernel.
 static int g_gemm_variant = 0;
 void set_predict_gemm_waves(int v) { g_gemm_variant = v; }
@@ -267,15 +318,17 @@ void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, con
 #define SPX_GO(NW_, STG_, ABL_)                                                                               \
     launch_gemm_variant<NW_, STG_, ABL_>(s, grid, lds, WT, Kst, gamma, part_ss, part_bg, Np, Mc, nh, ncb, nrb, \
                                          gammaS, S, part_bgS)
-    const int v = (S > 0) ? 4 : g_gemm_variant;   // the fantasy epilogue exists in the 4-wave kernel
+    const int v = (S > 0) ? 0 : g_gemm_variant;   // the fantasy epilogue exists in the 4-wave kernels
     switch (v) {
         case 8:  SPX_GO(8, 0, 0); break;
         case 14: SPX_GO(4, 1, 0); break;
         case 18: SPX_GO(8, 1, 0); break;
+        case 24: SPX_GO(4, 2, 0); break;
         case 41: SPX_GO(4, 0, 1); break;
         case 42: SPX_GO(4, 0, 2); break;
         case 43: SPX_GO(4, 0, 3); break;
-        default: SPX_GO(4, 0, 0); break;
+        case 4:  SPX_GO(4, 0, 0); break;
+        default: SPX_GO(4, 1, 0); break;   // production: 4 waves, LDS-DMA staging (measured fastest)
     }
 #undef SPX_GO
 }
