@@ -66,9 +66,9 @@ struct spx_handle {
     int device = 0;
     bool inited = false;
     hipStream_t stream = nullptr;    // main stream (also the only one the factorization uses)
-    hipStream_t stream2 = nullptr;   // second stream: EI work items alternate between the two so that
-                                     // one launch's tail overlaps the next launch's head
-    hipEvent_t ev_sync[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stream2 = nullptr;   // optional producer stream (option "streams" = 2): K(X*,X) of the next
+                                     // work item is generated (VALU) while the GEMM of the current one runs (MFMA)
+    hipEvent_t ev_sync[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
     int64_t N = 0, M = 0, index_base = 0;
     int D = 0, Dp = 0, Np = 0, H = 0;
@@ -109,7 +109,7 @@ static int ensure_init(spx_handle* h)
     if (!h->inited) {
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev_sync[i], hipEventDisableTiming));
+        for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev_sync[i], hipEventDisableTiming));
         h->inited = true;
     }
     return SPX_OK;
@@ -198,7 +198,7 @@ void spx_destroy(spx_handle* h)
                           &h->am_out_val, &h->am_out_idx, &h->scratch};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(h->ev_sync[i]);
+        for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
         (void)hipStreamDestroy(h->stream);
         (void)hipStreamDestroy(h->stream2);
     }
@@ -523,7 +523,13 @@ int spx_ei_run(spx_handle* h, int32_t flags)
 
     const double* ls = h->hyp.d() + 3;
     const size_t nn = (size_t)Np * Np;
-    hipStream_t strm[2] = {h->stream, ns == 2 ? h->stream2 : h->stream};
+    // Streams: G (consumer: predict GEMM + EI finalize) and P (producer: candidate scaling and
+    // K(X*,X)).  With one stream P == G and everything is in order.  With two, the K(X*,X)
+    // staging buffer is double-buffered per work item and item i+1 is produced while item i is
+    // consumed: the producer kernels are VALU/store-bound, the GEMM is MFMA-bound, and at 152 /
+    // 178 VGPRs one producer wave fits next to the two GEMM waves of a SIMD.
+    // events: [0..1] K* of buffer b ready, [2..3] buffer b consumed, [4..5] chunk parity consumed
+    hipStream_t G = h->stream, P = (ns == 2) ? h->stream2 : h->stream;
     int item = 0, chunk = 0;
     for (int64_t c0 = 0; c0 < Mp; c0 += Mc, ++chunk) {
         const int mc = (int)std::min<int64_t>(Mc, Mp - c0);       // multiple of 128
@@ -533,54 +539,55 @@ int spx_ei_run(spx_handle* h, int32_t flags)
         double* Cs = h->Cs[par].d();
         double* s2 = h->s2[par].d();
         double* tm = per_sec ? h->time_m[par].d() : nullptr;
-        // the buffers of this parity were last read two chunks ago by work on the second stream
-        if (ns == 2 && chunk >= 2) HIPCHK(hipStreamWaitEvent(s, h->ev_sync[2 + par], 0));
+        // the chunk-level buffers of this parity were last read (by EI finalize on G) two chunks ago
+        if (ns == 2 && chunk >= 2) HIPCHK(hipStreamWaitEvent(P, h->ev_sync[4 + par], 0));
         if (per_sec) {
             // log-duration GP: predicted duration of every candidate of the chunk, all draws in one launch
-            TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls + (size_t)H * hs, hs, H, 2.0, Cs, s2));
-            TIMED(ST_CROSS_MEAN, launch_cross_mean(s, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np, Cs, s2,
-                                                   h->htab.d() + (size_t)H * SPX_HT, h->alpha.d() + (size_t)H * Np, tm,
-                                                   (int)N, Np, mc, Dp, H));
+            TIMED_S(ST_SCALE, P, launch_scale_rows(P, xc, nreal, mc, D, Dp, ls + (size_t)H * hs, hs, H, 2.0, Cs, s2));
+            TIMED_S(ST_CROSS_MEAN, P, launch_cross_mean(P, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np, Cs, s2,
+                                                        h->htab.d() + (size_t)H * SPX_HT, h->alpha.d() + (size_t)H * Np, tm,
+                                                        (int)N, Np, mc, Dp, H));
         }
         if (per_sec && keep_mom)   // predicted durations [H][mc] -> [H][Mp] for spx_get_time_mean
             HIPCHK(hipMemcpy2DAsync(h->mom_t.d() + c0, (size_t)Mp * 8, tm, (size_t)mc * 8,
-                                    (size_t)std::min<int64_t>(mc, Mp - c0) * 8, (size_t)H, hipMemcpyDeviceToDevice, s));
+                                    (size_t)std::min<int64_t>(mc, Mp - c0) * 8, (size_t)H, hipMemcpyDeviceToDevice, P));
         // 2 * cand / ls and |cand / ls|^2 for every draw (one launch per chunk)
-        TIMED(ST_SCALE, launch_scale_rows(s, xc, nreal, mc, D, Dp, ls, hs, H, 2.0, Cs, s2));
-        if (ns == 2) {
-            HIPCHK(hipEventRecord(h->ev_sync[par], s));
-            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_sync[par], 0));
-        }
+        TIMED_S(ST_SCALE, P, launch_scale_rows(P, xc, nreal, mc, D, Dp, ls, hs, H, 2.0, Cs, s2));
         for (int h0 = 0; h0 < H; h0 += Hb, ++item) {
             const int nhb = std::min(Hb, H - h0);
             const int k = (ns == 2) ? (item & 1) : 0;
-            hipStream_t sk = strm[k];
-            TIMED_S(ST_COV_CROSS, sk, launch_cov_cross(sk, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
-                                                       Cs + (size_t)h0 * mc * Dp, s2 + (size_t)h0 * mc,
-                                                       h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb));
-            TIMED_S(ST_PREDICT_GEMM, sk, launch_predict_gemm(sk, h->WT.d() + (size_t)h0 * nn, h->Kst[k].d(),
-                                                             h->gamma.d() + (size_t)h0 * Np, h->part_ss[k].d(),
-                                                             h->part_bg[k].d(), Np, mc, nhb,
-                                                             S > 0 ? h->gammaS.d() + (size_t)h0 * S * Np : nullptr, S,
-                                                             S > 0 ? h->part_bgS[k].d() : nullptr));
+            if (ns == 2 && item >= 2) HIPCHK(hipStreamWaitEvent(P, h->ev_sync[2 + k], 0));   // buffer k consumed
+            TIMED_S(ST_COV_CROSS, P, launch_cov_cross(P, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
+                                                      Cs + (size_t)h0 * mc * Dp, s2 + (size_t)h0 * mc,
+                                                      h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb));
+            if (ns == 2) {
+                HIPCHK(hipEventRecord(h->ev_sync[k], P));
+                HIPCHK(hipStreamWaitEvent(G, h->ev_sync[k], 0));
+            }
+            TIMED_S(ST_PREDICT_GEMM, G, launch_predict_gemm(G, h->WT.d() + (size_t)h0 * nn, h->Kst[k].d(),
+                                                            h->gamma.d() + (size_t)h0 * Np, h->part_ss[k].d(),
+                                                            h->part_bg[k].d(), Np, mc, nhb,
+                                                            S > 0 ? h->gammaS.d() + (size_t)h0 * S * Np : nullptr, S,
+                                                            S > 0 ? h->part_bgS[k].d() : nullptr));
             if (S > 0)
-                TIMED_S(ST_EI_FINALIZE, sk, launch_ei_finalize_fant(sk, h->part_ss[k].d(), h->part_bgS[k].d(),
-                                                                    h->htab.d() + (size_t)h0 * SPX_HT,
-                                                                    h->bests.d() + (size_t)h0 * S,
-                                                                    per_sec ? tm + (size_t)h0 * mc : nullptr,
-                                                                    h->ei_draw.d(), nrb, mc, nhb, S, c0, M, Mp, h0));
+                TIMED_S(ST_EI_FINALIZE, G, launch_ei_finalize_fant(G, h->part_ss[k].d(), h->part_bgS[k].d(),
+                                                                   h->htab.d() + (size_t)h0 * SPX_HT,
+                                                                   h->bests.d() + (size_t)h0 * S,
+                                                                   per_sec ? tm + (size_t)h0 * mc : nullptr,
+                                                                   h->ei_draw.d(), nrb, mc, nhb, S, c0, M, Mp, h0));
             else
-                TIMED_S(ST_EI_FINALIZE, sk, launch_ei_finalize(sk, h->part_ss[k].d(), h->part_bg[k].d(),
-                                                               h->htab.d() + (size_t)h0 * SPX_HT,
-                                                               per_sec ? tm + (size_t)h0 * mc : nullptr, h->best,
-                                                               h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
-                                                               keep_mom ? h->mom_v.d() : nullptr, nrb, mc, nhb, c0, M, Mp, h0));
+                TIMED_S(ST_EI_FINALIZE, G, launch_ei_finalize(G, h->part_ss[k].d(), h->part_bg[k].d(),
+                                                              h->htab.d() + (size_t)h0 * SPX_HT,
+                                                              per_sec ? tm + (size_t)h0 * mc : nullptr, h->best,
+                                                              h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
+                                                              keep_mom ? h->mom_v.d() : nullptr, nrb, mc, nhb, c0, M, Mp, h0));
+            if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[2 + k], G));
         }
-        if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[2 + par], h->stream2));
+        if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[4 + par], G));
     }
-    if (ns == 2) {  // join: the reduction below needs every EI value
-        HIPCHK(hipEventRecord(h->ev_sync[0], h->stream2));
-        HIPCHK(hipStreamWaitEvent(s, h->ev_sync[0], 0));
+    if (ns == 2 && per_sec && keep_mom) {   // the duration copies ran on P
+        HIPCHK(hipEventRecord(h->ev_sync[0], P));
+        HIPCHK(hipStreamWaitEvent(G, h->ev_sync[0], 0));
     }
     TIMED(ST_MEAN_ARGMAX, {
         launch_mean_over_draws(s, h->ei_draw.d(), h->ei_mean.d(), M, Mp, H);

@@ -516,3 +516,21 @@ def test_chooser_with_ndev(golden_dir, tmp_path):
     ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=10,ndev=1,device=0")
     npr.seed(int(g["seed"]))
     assert ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"]) == int(g["job"])
+
+
+def test_two_stream_mode_is_bit_identical(eng):
+    """Option streams=2 (K(X*,X) of item i+1 produced on a second stream while item i is
+    consumed) must not change a single bit."""
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(260, 5000, 7, 5, 71, per_sec=True)
+    try:
+        eng.set_option("kstar_budget_bytes", 384 * 1024 * 8)     # several chunks and items
+        a = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        ap = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+        eng.set_option("streams", 2)
+        b = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        bp = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+    finally:
+        eng.set_option("streams", 1)
+        eng.set_option("kstar_budget_bytes", 0)
+    assert a[0] == b[0] and np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
+    assert ap[0] == bp[0] and np.array_equal(ap[3], bp[3])
