@@ -66,8 +66,9 @@ def pmc_traffic(workload):
     path = os.path.join(ROOT, "profiles", "r01_%s_rocprof_summary.json" % workload)
     try:
         with open(path) as fh:
-            k = json.load(fh)["kernels"]["k_predict_gemm"]
-        return float(k["hbm_bytes_per_launch_corrected"]), os.path.relpath(path, ROOT)
+            kernels = json.load(fh)["kernels"]
+        name = [n for n in kernels if n.startswith("k_predict_gemm")][0]   # template args are part of the name
+        return float(kernels[name]["hbm_bytes_per_launch_corrected"]), os.path.relpath(path, ROOT)
     except Exception:
         return None, None
 
