@@ -67,6 +67,7 @@ class GPEIBase(object):
         self.gpu_logprob = str(gpu_logprob)
         # same choice for the EI + gradient objective of the local refinement (spx_ei_grad)
         self.gpu_refine = str(gpu_refine)
+        self.lookahead = 4        # slice-sampler proposals evaluated speculatively per GPU call
         self._lp_key = None
         self.D = -1
         self._eng = None          # created lazily in next(): never before a fork, never pickled
@@ -152,6 +153,41 @@ class GPEIBase(object):
         eng.set_hypers(np.concatenate(([mean, noise, amp2], np.asarray(ls, dtype=float)))[None, :])
         return float(eng.gp_logprob(raise_not_pd=True)[0])
 
+    def data_logprob_many(self, comp, vals, rows):
+        """The data term for several hyper rows [mean, noise, amp2, ls...] in ONE GPU call
+        (the batched factorisation has the latency of a single one).  Returns (values, not_pd)."""
+        eng = self.engine()
+        key = (id(comp), id(vals), comp.shape, float(vals[0]), float(vals[-1]))
+        if self._lp_key != key:
+            eng.set_observations(comp, vals)
+            self._lp_key = key
+        eng.set_hypers(rows)
+        lp = eng.gp_logprob()
+        return lp, np.isneginf(lp)
+
+    def _speculative_logprob(self, comp, vals, to_row, finish):
+        """Adapter for util.slice_sample_batched: `to_row(x)` gives the hyper row to evaluate or
+        None when x is rejected a priori (-inf without touching the GP, as the reference's
+        closures do); `finish(x, data_lp)` adds the priors."""
+        def many(xs):
+            rows, where = [], []
+            for k, x in enumerate(xs):
+                r = to_row(x)
+                if r is not None:
+                    rows.append(r)
+                    where.append(k)
+            values = [-np.inf] * len(xs)
+            errors = [None] * len(xs)
+            if rows:
+                lp, bad = self.data_logprob_many(comp, vals, np.array(rows))
+                for j, k in enumerate(where):
+                    if bad[j]:   # spla.cholesky would raise here -- only if the sampler really gets to it
+                        errors[k] = np.linalg.LinAlgError("covariance not positive definite")
+                    else:
+                        values[k] = finish(xs[k], lp[j])
+            return util._LazyValues(values, errors)
+        return many
+
     # -- hyper-parameter sampling (host; GPEIChooser.py:268-346) -----------------
     def _amp2_logprior(self, amp2, scale):
         a = np.sqrt(amp2) if self.amp2_prior_on_sqrt else amp2
@@ -163,29 +199,57 @@ class GPEIBase(object):
         lo, hi = np.min(vals), np.max(vals)
         check_mean = (not noiseless) or self.noiseless_checks_mean
         sqrt_prior = self.amp2_prior_on_sqrt if on_sqrt is None else on_sqrt
+        ls = np.asarray(ls, dtype=float)
 
-        def logprob(h):
+        def admissible(h):
             mean, amp2 = h[0], h[1]
             noise = 1e-3 if noiseless else h[2]
             if check_mean and (mean > hi or mean < lo):
-                return -np.inf
+                return None
             if amp2 < 0 or noise < 0:
-                return -np.inf
-            lp = self.data_logprob(comp, vals, mean, amp2, noise, ls)
+                return None
+            return mean, amp2, noise
+
+        def priors(h, lp):
+            amp2 = h[1]
+            noise = 1e-3 if noiseless else h[2]
             if not noiseless:
                 lp += np.log(np.log(1 + (noise_scale / noise) ** 2))
             a = np.sqrt(amp2) if sqrt_prior else amp2
             lp -= 0.5 * (np.log(a) / amp2_scale) ** 2
             return lp
 
-        new = util.slice_sample(np.array(cur, dtype=float), logprob, compwise=False)
+        def logprob(h):
+            ok = admissible(h)
+            if ok is None:
+                return -np.inf
+            return priors(h, self.data_logprob(comp, vals, ok[0], ok[1], ok[2], ls))
+
+        start = np.array(cur, dtype=float)
+        if self._use_gpu_logprob(comp.shape[0]):
+            def to_row(h):
+                ok = admissible(h)
+                return None if ok is None else np.concatenate(([ok[0], ok[2], ok[1]], ls))
+            new = util.slice_sample_batched(start, self._speculative_logprob(comp, vals, to_row, priors),
+                                            compwise=False, lookahead=self.lookahead)
+        else:
+            new = util.slice_sample(start, logprob, compwise=False)
         return new[0], new[1], (1e-3 if noiseless else new[2])
 
     def _draw_ls(self, comp, vals, mean, amp2, noise, ls, max_ls):
+        def inside(cand_ls):
+            return not (np.any(cand_ls < 0) or np.any(cand_ls > max_ls))
+
         def logprob(cand_ls):
-            if np.any(cand_ls < 0) or np.any(cand_ls > max_ls):
+            if not inside(cand_ls):
                 return -np.inf
             return self.data_logprob(comp, vals, mean, amp2, noise, cand_ls)
+
+        if self._use_gpu_logprob(comp.shape[0]):
+            def to_row(cand_ls):
+                return np.concatenate(([mean, noise, amp2], cand_ls)) if inside(cand_ls) else None
+            return util.slice_sample_batched(ls, self._speculative_logprob(comp, vals, to_row, lambda x, lp: lp),
+                                             compwise=True, lookahead=self.lookahead)
         return util.slice_sample(ls, logprob, compwise=True)
 
     def sample_hypers(self, comp, vals):
