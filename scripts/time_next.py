@@ -14,7 +14,8 @@ comp, cand, vals, _ = synthetic_problem(N, M, D, 1, 9)
 grid = np.vstack((comp, cand)); values = np.concatenate((vals, np.full(M, np.nan)))
 durations = np.ones(N + M)
 complete = np.arange(N); candidates = np.arange(N, N + M); pending = np.array([], dtype=int)
-for label, extra in (("gpu sampler+refine", "gpu_logprob=1,gpu_refine=1"), ("host sampler+refine", "gpu_logprob=0,gpu_refine=0")):
+LA = os.environ.get("SPX_LOOKAHEAD", "4")
+for label, extra in (("gpu sampler+refine", "gpu_logprob=1,gpu_refine=1,lookahead=" + LA), ("host sampler+refine", "gpu_logprob=0,gpu_refine=0")):
     if label.startswith("host") and len(sys.argv) > 4 and sys.argv[4] == "nohost":
         continue
     ch = GPEIOptChooser.init(tempfile.mkdtemp(), "mcmc_iters=4,burnin=2,grid_subset=4,use_multiprocessing=0," + extra)

@@ -48,7 +48,7 @@ class GPEIBase(object):
 
     def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
                  noiseless=False, device=0, ndev=1, lib=None, gpu_logprob="auto", gpu_refine="auto",
-                 **unused):
+                 lookahead=8, **unused):
         if covar != "Matern52":
             # the HIP path implements the ARD Matern-5/2 kernel named by the north star
             raise ValueError("spearmint_amd choosers support covar=Matern52 only (got %r)" % (covar,))
@@ -67,7 +67,7 @@ class GPEIBase(object):
         self.gpu_logprob = str(gpu_logprob)
         # same choice for the EI + gradient objective of the local refinement (spx_ei_grad)
         self.gpu_refine = str(gpu_refine)
-        self.lookahead = 4        # slice-sampler proposals evaluated speculatively per GPU call
+        self.lookahead = max(1, int(lookahead))   # slice-sampler proposals evaluated speculatively per GPU call
         self._lp_key = None
         self.D = -1
         self._eng = None          # created lazily in next(): never before a fork, never pickled
