@@ -69,6 +69,7 @@ struct spx_handle {
     hipStream_t stream2 = nullptr;   // optional producer stream (option "streams" = 2): K(X*,X) of the next
                                      // work item is generated (VALU) while the GEMM of the current one runs (MFMA)
     hipEvent_t ev_sync[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // whole-stage timers (factor / ei_run)
 
     int64_t N = 0, M = 0, index_base = 0;
     int D = 0, Dp = 0, Np = 0, H = 0;
@@ -110,6 +111,8 @@ static int ensure_init(spx_handle* h)
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
         for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev_sync[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&h->ev_t0));
+        HIPCHK(hipEventCreate(&h->ev_t1));
         h->inited = true;
     }
     return SPX_OK;
@@ -199,6 +202,8 @@ void spx_destroy(spx_handle* h)
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
+        (void)hipEventDestroy(h->ev_t0);
+        (void)hipEventDestroy(h->ev_t1);
         (void)hipStreamDestroy(h->stream);
         (void)hipStreamDestroy(h->stream2);
     }
@@ -338,9 +343,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
 
     hipStream_t s = h->stream;
     h->ev_used = 0;
-    hipEvent_t t0, t1;
-    HIPCHK(hipEventCreate(&t0));
-    HIPCHK(hipEventCreate(&t1));
+    hipEvent_t t0 = h->ev_t0, t1 = h->ev_t1;
     HIPCHK(hipMemcpyAsync(h->hyp.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->htab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(t0, s));
@@ -374,8 +377,6 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     HIPCHK(hipGetLastError());
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, t0, t1);
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     if (h->timing) {
         ev_collect(h);
         h->st_ms[ST_FACTOR_TOTAL] += ms; h->st_n[ST_FACTOR_TOTAL] += 1;
@@ -516,9 +517,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
     hipStream_t s = h->stream;
     if (flags & SPX_FLAG_TIMING) h->timing = true;
     h->ev_used = 0;
-    hipEvent_t t0, t1;
-    HIPCHK(hipEventCreate(&t0));
-    HIPCHK(hipEventCreate(&t1));
+    hipEvent_t t0 = h->ev_t0, t1 = h->ev_t1;
     HIPCHK(hipEventRecord(t0, s));
 
     const double* ls = h->hyp.d() + 3;
@@ -601,8 +600,6 @@ int spx_ei_run(spx_handle* h, int32_t flags)
     HIPCHK(hipGetLastError());
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, t0, t1);
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     if (h->timing) {
         ev_collect(h);
         h->st_ms[ST_EI_RUN_TOTAL] += ms; h->st_n[ST_EI_RUN_TOTAL] += 1;
