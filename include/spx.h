@@ -144,7 +144,9 @@ int spx_gp_logprob(spx_handle* h, double* out);
 /* Objective of the local refinement (GPEIOptChooser.py:360-440; "next" row 3): at ONE point
  * (D doubles) the summed negative EI over the resident draws and its gradient, in the
  * reference's scaling (its grad_xp carries a factor one half).  Needs spx_factor or a
- * previous spx_ei_grid; observations without pending experiments.                       */
+ * previous spx_ei_grid; observations without pending experiments.  When a time model was
+ * factored (spx_set_time_model / spx_ei_per_sec_grid) the objective is EI per second and
+ * its gradient (GPEIperSecChooser.py:349-434).                                           */
 int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad /* D */);
 /* which draw / pivot failed in the last SPX_ERR_NOT_PD                         */
 int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot);

@@ -101,6 +101,7 @@ class GPEIperSecChooser(GPEIBase):
     def ei_per_s_over_hypers_gpu(self, comp, pend, cand, vals, durs):
         rows, trows = self._paired_samples()
         self._lp_key = None
+        self._resident_plain = pend.shape[0] == 0   # the engine then holds exactly (comp, rows, trows)
         if pend.shape[0] > 0:
             return self._ei_per_s_with_pending(comp, pend, cand, vals, durs, rows, trows)
         idx, val, mean, draws = self.engine().ei_per_sec_grid(comp, vals, durs, cand, rows, trows,
@@ -136,18 +137,28 @@ class GPEIperSecChooser(GPEIBase):
         return int(np.argmax(mean)), mean
 
     def _refine(self, points, comp, vals, durs):
-        rows, trows = (self.hyper_samples[:self.mcmc_iters],
-                       (self.time_hyper_samples[:self.mcmc_iters] if self.ref_compat
-                        else self.time_hyper_samples[-self.mcmc_iters:]))
-        models = [hostgp.PerSecPointModel(comp, vals, durs, h, t) for h, t in zip(rows, trows)]
+        """L-BFGS-B on the summed EI per second (:223-230; the reference ignores pending jobs
+        here).  On the GPU the objective uses the dual factorisation the first pass left
+        resident (spx_ei_grad); the bug-compatible mode pairs the draws as the reference does,
+        which the resident pairing does not reproduce, so it stays on the host."""
+        if self._use_gpu_refine(comp.shape[0]) and not self.ref_compat and self._resident_plain:
+            eng = self.engine()
 
-        def objective(x):
-            total, grad = 0.0, np.zeros(x.shape[0])
-            for m in models:
-                e, g = m.neg_ei_and_grad(x)
-                total += e
-                grad = grad + g
-            return total, grad
+            def objective(x):
+                return eng.ei_grad(x)
+        else:
+            rows, trows = (self.hyper_samples[:self.mcmc_iters],
+                           (self.time_hyper_samples[:self.mcmc_iters] if self.ref_compat
+                            else self.time_hyper_samples[-self.mcmc_iters:]))
+            models = [hostgp.PerSecPointModel(comp, vals, durs, h, t) for h, t in zip(rows, trows)]
+
+            def objective(x):
+                total, grad = 0.0, np.zeros(x.shape[0])
+                for m in models:
+                    e, g = m.neg_ei_and_grad(x)
+                    total += e
+                    grad = grad + g
+                return total, grad
 
         bounds = [(0, 1)] * comp.shape[1]
         out = np.array(points, dtype=float, copy=True)

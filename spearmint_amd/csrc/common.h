@@ -60,7 +60,8 @@ void launch_point_cov(hipStream_t s, const double* Xs, const double* s1, const d
 void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, const double* htab,
                          const double* alpha, const double* kvec, const double* dkdr2,
                          const double* tvec, const double* zvec, const double* x, double best,
-                         double* out, int N, int Np, int D, int Dp, int nh);
+                         double* out, int N, int Np, int D, int Dp, int nh, const double* kt = nullptr,
+                         const double* dkt = nullptr);
 
 // predict_kernels.hip
 void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,

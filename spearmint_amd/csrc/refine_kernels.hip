@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256) void k_point_finish(
     const double* __restrict__ Xs, const double* __restrict__ hyp, const double* __restrict__ htab,
     const double* __restrict__ alpha, const double* __restrict__ kvec, const double* __restrict__ dkdr2,
     const double* __restrict__ tvec, const double* __restrict__ zvec, const double* __restrict__ x,
-    double best, double* __restrict__ out, int N, int Np, int D, int Dp)
+    double best, double* __restrict__ out, int N, int Np, int D, int Dp,
+    // EI per second (GPEIperSecChooser.py:349-434): rows H..2H-1 of the tables hold the log-duration
+    // GP; kt / dkt are its k and dk/dr2 at x.  Null -> plain EI.
+    int H, const double* __restrict__ kt, const double* __restrict__ dkt)
 {
     extern __shared__ double red[];   // [256] scratch for the block reductions
     __shared__ double sh_cdf, sh_w;
@@ -121,25 +124,60 @@ __global__ __launch_bounds__(256) void k_point_finish(
     }
     __syncthreads();
     const double g_m = -sh_cdf, g_s2 = sh_w;
+    // time model of this draw (row h + H)
+    const int ht = h + H;
+    double time_m = 1.0;
+    const double* lst = nullptr;
+    const double* aht = nullptr;
+    const double* kht = nullptr;
+    const double* dht = nullptr;
+    double amp2t = 0.0;
+    if (kt) {
+        lst = hyp + (size_t)ht * (3 + D) + 3;
+        aht = alpha + (size_t)ht * Np;
+        kht = kt + (size_t)h * Np;
+        dht = dkt + (size_t)h * Np;
+        amp2t = htab[ht * SPX_HT + 2];
+        double kat = 0.0;
+        for (int j = tid; j < N; j += 256) kat += kht[j] * aht[j];
+        kat = block_sum(kat);
+        time_m = exp(kat + htab[ht * SPX_HT + 0]);
+    }
+    const double ei = out[(size_t)h * (1 + D)];   // written by thread 0 above; visible after the barriers
     for (int d = 0; d < D; ++d) {
         const double xc = x[d] / ls[d];
-        double a1 = 0.0, a2 = 0.0;
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
         for (int j = tid; j < N; j += 256) {
             const double gj = dh[j] * (2.0 * (Xs[((size_t)h * Np + j) * Dp + d] - xc) * (1.0 / ls[d]));
             a1 += ah[j] * gj;
             a2 += zh[j] * gj;
+            if (kt) {
+                const double xct = x[d] / lst[d];
+                const double gt = dht[j] * (2.0 * (Xs[((size_t)ht * Np + j) * Dp + d] - xct) * (1.0 / lst[d]));
+                a3 += aht[j] * gt;
+            }
         }
         a1 = block_sum(a1);
         a2 = block_sum(a2);
-        if (tid == 0) out[(size_t)h * (1 + D) + 1 + d] = 0.5 * amp2 * (a1 * g_m + (-2.0 * a2) * g_s2);
+        if (kt) a3 = block_sum(a3);
+        if (tid == 0) {
+            double gd = 0.5 * amp2 * (a1 * g_m + (-2.0 * a2) * g_s2);
+            if (kt) {
+                const double gtd = 0.5 * amp2t * a3 * time_m;
+                gd = (time_m * gd - ei * gtd) / (time_m * time_m);
+            }
+            out[(size_t)h * (1 + D) + 1 + d] = gd;
+        }
     }
+    __syncthreads();
+    if (kt && tid == 0) out[(size_t)h * (1 + D)] = ei / time_m;
 }
 
 void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, const double* htab,
                          const double* alpha, const double* kvec, const double* dkdr2,
                          const double* tvec, const double* zvec, const double* x, double best,
-                         double* out, int N, int Np, int D, int Dp, int nh)
+                         double* out, int N, int Np, int D, int Dp, int nh, const double* kt, const double* dkt)
 {
     hipLaunchKernelGGL(k_point_finish, dim3(nh), dim3(256), 256 * sizeof(double), s, Xs, hyp, htab, alpha,
-                       kvec, dkdr2, tvec, zvec, x, best, out, N, Np, D, Dp);
+                       kvec, dkdr2, tvec, zvec, x, best, out, N, Np, D, Dp, nh, kt, dkt);
 }

@@ -90,7 +90,7 @@ struct spx_handle {
     // pending-experiment fantasies (spx_set_fantasies): S right-hand sides per draw
     int S = 0;
     DevBuf fantT, gammaS, bests, part_bgS[2];
-    DevBuf pt_x, pt_k, pt_dk, pt_t, pt_z, pt_out;   // spx_ei_grad work vectors
+    DevBuf pt_x, pt_k, pt_dk, pt_t, pt_z, pt_out, pt_kt, pt_dkt;   // spx_ei_grad work vectors
 
     double best_val = 0.0;
     int64_t best_idx = -1;
@@ -196,7 +196,7 @@ void spx_destroy(spx_handle* h)
                           &h->Cs[0], &h->s2[0], &h->Kst[0], &h->part_ss[0], &h->part_bg[0], &h->time_m[0],
                           &h->Cs[1], &h->s2[1], &h->Kst[1], &h->part_ss[1], &h->part_bg[1], &h->time_m[1],
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
-                          &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out,
+                          &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
                           &h->am_out_val, &h->am_out_idx, &h->scratch};
         for (DevBuf* b : bufs) b->release();
@@ -787,14 +787,24 @@ int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* 
     if ((rc = h->pt_t.reserve((size_t)H * Np * 8))) return rc;
     if ((rc = h->pt_z.reserve((size_t)H * Np * 8))) return rc;
     if ((rc = h->pt_out.reserve((size_t)H * (1 + D) * 8))) return rc;
+    const bool per_sec = (h->nmodels == 2);   // a time model was factored: EI per second (GPEIperSecChooser.py:349-434)
+    if (per_sec) {
+        if ((rc = h->pt_kt.reserve((size_t)H * Np * 8))) return rc;
+        if ((rc = h->pt_dkt.reserve((size_t)H * Np * 8))) return rc;
+    }
     hipStream_t s = h->stream;
     HIPCHK(hipMemcpyAsync(h->pt_x.p, point, (size_t)D * 8, hipMemcpyHostToDevice, s));
     launch_point_cov(s, h->Xs.d(), h->s1.d(), h->hyp.d(), h->htab.d(), h->pt_x.d(), h->pt_k.d(), h->pt_dk.d(),
                      (int)N, Np, D, Dp, H);
     launch_gemv_lower(s, h->WT.d(), h->pt_k.d(), h->pt_t.d(), Np, H);       // t = W k
     launch_alpha(s, h->WT.d(), h->pt_t.d(), h->pt_z.d(), Np, H);            // z = W^T t = K^-1 k
+    if (per_sec)   // k and dk/dr2 of the log-duration GP (table rows H..2H-1)
+        launch_point_cov(s, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np,
+                         h->hyp.d() + (size_t)H * (3 + D), h->htab.d() + (size_t)H * SPX_HT, h->pt_x.d(),
+                         h->pt_kt.d(), h->pt_dkt.d(), (int)N, Np, D, Dp, H);
     launch_point_finish(s, h->Xs.d(), h->hyp.d(), h->htab.d(), h->alpha.d(), h->pt_k.d(), h->pt_dk.d(),
-                        h->pt_t.d(), h->pt_z.d(), h->pt_x.d(), h->best, h->pt_out.d(), (int)N, Np, D, Dp, H);
+                        h->pt_t.d(), h->pt_z.d(), h->pt_x.d(), h->best, h->pt_out.d(), (int)N, Np, D, Dp, H,
+                        per_sec ? h->pt_kt.d() : nullptr, per_sec ? h->pt_dkt.d() : nullptr);
     std::vector<double> out((size_t)H * (1 + D));
     HIPCHK(hipMemcpyAsync(out.data(), h->pt_out.p, out.size() * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

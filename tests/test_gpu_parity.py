@@ -534,3 +534,19 @@ def test_two_stream_mode_is_bit_identical(eng):
         eng.set_option("kstar_budget_bytes", 0)
     assert a[0] == b[0] and np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
     assert ap[0] == bp[0] and np.array_equal(ap[3], bp[3])
+
+
+def test_ei_per_second_grad_matches_host_model(eng):
+    from spearmint_amd import hostgp
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(200, 60, 5, 3, 81, per_sec=True)
+    eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th)
+    models = [hostgp.PerSecPointModel(comp, vals, log_durs, (h[0], h[1], h[2], h[3:]), (t[0], t[1], t[2], t[3:]))
+              for h, t in zip(hypers, th)]
+    for x in [cand[2], comp[9] + 1e-3, np.random.RandomState(3).rand(5)]:
+        f_ref, g_ref = 0.0, np.zeros(5)
+        for m in models:
+            e, g = m.neg_ei_and_grad(x)
+            f_ref += e; g_ref = g_ref + g
+        f, g = eng.ei_grad(x)
+        assert np.isclose(f, f_ref, rtol=1e-7, atol=1e-300)
+        assert np.allclose(g, g_ref, rtol=1e-6, atol=1e-9 * np.abs(g_ref).max())
