@@ -22,7 +22,6 @@
 
 #define NB SPX_NB
 #define LDP 66   // LDS row stride (doubles) for MFMA operand tiles: 16 rows x 2 cols hit 32 distinct 8-byte banks
-#define LDS_S 65 // LDS row stride for the lane-per-row factorization (column access conflict-free)
 
 __device__ __forceinline__ double readlane_f64(double v, int src)
 {
