@@ -14,6 +14,9 @@
 #include "common.h"
 
 #define SQRT5 2.23606797749978969641  // == np.sqrt(5.0) (gp.py:32)
+#ifndef SPX_COV_HOIST
+#define SPX_COV_HOIST 1   // keep the column-side fragments in registers across row tiles
+#endif
 
 // ---------------------------------------------------------------------------
 // x / ls, row norms.   One thread per (row, draw).
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     const double* __restrict__ Xs, const double* __restrict__ s1,
     const double* __restrict__ Cs, const double* __restrict__ s2,
     const double* __restrict__ htab, const double* __restrict__ alpha,
-    double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo)
+    double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int rows_per_wg)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     for (int nt = 0; nt < 4; ++nt) s2v[nt] = s2[(size_t)h * Mc + c0 + 16 * nt + li];
 
     double bf[4][QC];
-    if (nchunks == 1) {
+    if (nchunks == 1 && SPX_COV_HOIST) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const double* p = Ch + (size_t)(c0 + 16 * nt + li) * Dp + g * Q;
@@ -162,8 +165,10 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     // MODE 2 accumulates sum_j k[j][c] alpha[j] for this lane's column(s)
     double colsum[4] = {0.0, 0.0, 0.0, 0.0};
 
-    const int jbeg = (MODE == 2) ? 0 : blockIdx.y * 128;
-    const int jend = (MODE == 2) ? Np : jbeg + 128;
+    // MODE 0/1: a workgroup covers `rows_per_wg` rows (a multiple of 128) so that the prologue
+    // (column-side fragment and norm loads, ~1-2 us of latency) is amortised over many row tiles
+    const int jbeg = (MODE == 2) ? 0 : blockIdx.y * rows_per_wg;
+    const int jend = (MODE == 2) ? Np : min(Np, jbeg + rows_per_wg);
     for (int j0 = jbeg + wave * 16; j0 < jend; j0 += 64) {
         d4 acc[4];
 #pragma unroll
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_cov(
             const double* pa = Xh + (size_t)(j0 + li) * Dp + g * Q + ch * QC;
 #pragma unroll
             for (int q = 0; q < QC; ++q) af[q] = pa[q];
-            if (nchunks > 1) {
+            if (nchunks > 1 || !SPX_COV_HOIST) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const double* p = Ch + (size_t)(c0 + 16 * nt + li) * Dp + g * Q + ch * QC;
@@ -240,11 +245,12 @@ static void launch_cov_mode(hipStream_t s, const double* Xs, const double* s1, c
                             int N, int Np, int Mc, int Dp, int nh, int64_t ldo)
 {
     const int Q = Dp / 4;
-    dim3 grid(Mc / 64, (MODE == 2) ? 1 : Np / 128, nh);
+    const int rows_per_wg = (Np >= 1024) ? 512 : ((Np >= 256) ? 256 : 128);
+    dim3 grid(Mc / 64, (MODE == 2) ? 1 : (Np + rows_per_wg - 1) / rows_per_wg, nh);
     dim3 block(256);
 #define SPX_COV_LAUNCH(QC_)                                                                        \
     hipLaunchKernelGGL((k_cov<MODE, QC_>), grid, block, 0, s, Xs, s1, Cs, s2, htab, alpha, out, N, \
-                       Np, Mc, Dp, Q / QC_, ldo)
+                       Np, Mc, Dp, Q / QC_, ldo, rows_per_wg)
     if (Q == 1) SPX_COV_LAUNCH(1);
     else if (Q == 2) SPX_COV_LAUNCH(2);
     else if (Q == 4) SPX_COV_LAUNCH(4);
