@@ -23,30 +23,53 @@
 //   xs[h][row][d]  = factor * (x[row][d] / ls[h][d])     (0 for pad rows / dims)
 //   sumsq[h][row]  = sum_d (x[row][d] / ls[h][d])^2
 // ---------------------------------------------------------------------------
+#define SR_DC 32   // feature columns per LDS pass
 __global__ __launch_bounds__(256) void k_scale_rows(
     const double* __restrict__ x, int64_t n, int64_t n_pad, int D, int Dp,
     const double* __restrict__ ls, int ls_stride, double factor,
     double* __restrict__ xs, double* __restrict__ sumsq)
 {
 #pragma clang fp contract(off)
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 256 rows per workgroup, staged through LDS so that both the read of x (rows of D doubles)
+    // and the write of xs (rows of Dp doubles) are contiguous across the wave; each thread then
+    // owns one row and accumulates its squared norm left to right.
+    __shared__ double T[256][SR_DC + 1];
+    const int tid = threadIdx.x;
     const int h = blockIdx.y;
-    if (row >= n_pad) return;
-    double* o = xs + ((size_t)h * n_pad + row) * Dp;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int rows = (int)((n_pad - row0 < 256) ? (n_pad - row0) : 256);
+    const int64_t row = row0 + tid;
     const double* lsh = ls + (size_t)h * ls_stride;
+    double* o = xs + ((size_t)h * n_pad + row0) * Dp;
     double acc = 0.0;
-    if (row < n) {
-        const double* xr = x + (size_t)row * D;
-        for (int d = 0; d < D; ++d) {
-            const double v = xr[d] / lsh[d];
-            acc = acc + v * v;
-            o[d] = factor * v;
+    for (int d0 = 0; d0 < Dp; d0 += SR_DC) {
+        const int dc = (Dp - d0 < SR_DC) ? (Dp - d0) : SR_DC;                    // output columns
+        const int dr = (D - d0 < 0) ? 0 : ((D - d0 < SR_DC) ? (D - d0) : SR_DC);  // real columns
+        for (int e = tid; e < rows * dr; e += 256) {
+            const int r = e / dr, c = e - r * dr;
+            T[r][c] = (row0 + r < n) ? x[(size_t)(row0 + r) * D + d0 + c] : 0.0;
         }
-        for (int d = D; d < Dp; ++d) o[d] = 0.0;
-    } else {
-        for (int d = 0; d < Dp; ++d) o[d] = 0.0;
+        __syncthreads();
+        if (tid < rows) {
+            if (row < n) {
+                for (int c = 0; c < dr; ++c) {
+                    const double v = T[tid][c] / lsh[d0 + c];
+                    acc = acc + v * v;
+                    T[tid][c] = factor * v;
+                }
+                for (int c = dr; c < dc; ++c) T[tid][c] = 0.0;
+            } else {
+                for (int c = 0; c < dc; ++c) T[tid][c] = 0.0;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < rows * dc; e += 256) {
+            const int r = e / dc, c = e - r * dc;
+            o[(size_t)r * Dp + d0 + c] = T[r][c];
+        }
+        __syncthreads();
     }
-    sumsq[(size_t)h * n_pad + row] = acc;
+    if (tid < rows) sumsq[(size_t)h * n_pad + row] = acc;
 }
 
 void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp,
