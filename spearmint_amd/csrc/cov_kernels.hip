@@ -81,78 +81,105 @@ void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad,
                        factor, xs, sumsq);
 }
 
-// sqrt(x) for x >= 0 (x = 0 allowed), ~1 ulp: v_rsq_f64 seed + two coupled Newton steps.
-// Leaner than the library sqrt (no denormal rescaling / special-case selects): this epilogue
-// runs once per covariance entry, 4e8 times per draw at C3.
-__device__ __forceinline__ double sqrt_nonneg(double x)
+// The epilogue below runs once per covariance entry (4e8 times per draw at C3).  What bounds
+// k_cov on gfx950 is the fp64 FMA units, which the fp64 MFMA and the fp64 VALU instructions
+// appear to share (vector and matrix fp64 peaks are the same 78.6 TFLOP/s, and a v_mfma_f64_16x16x4 holds
+// the unit for 64 cycles): PMC at C3 shows the unit 31 % busy with the Gram MFMAs + 44 % with
+// VALU work, and the kernel time did not move with the stores removed, with a balanced
+// one-round grid, with the chains interleaved four ways, or with the next tile's MFMAs
+// software-pipelined under the epilogue -- only with fewer instructions.  So the helpers carry
+// no special-case selects: matern52_corr clamps r^2 into a range where they need none and
+// restores NaN / inf inputs with one fma at the end.  They work on W independent values in
+// lock step (every stage is a loop over W) so that consecutive instructions are independent.
+
+// sqrt(x) for x in [1e-300, 1e300], ~1 ulp: v_rsq_f64 seed + two coupled Newton steps.
+template <int W>
+__device__ __forceinline__ void sqrt_pos(const double (&x)[W], double (&out)[W])
 {
-    const double y0 = __builtin_amdgcn_rsq(x);
-    double g = x * y0;
-    double hh = 0.5 * y0;
-    double r = fma(-hh, g, 0.5);
-    g = fma(g, r, g);
-    hh = fma(hh, r, hh);
-    const double d = fma(-g, g, x);
-    g = fma(d, hh, g);
-    return (x > 0.0) ? g : x;   // x == 0 -> 0 (rsq(0) = inf), NaN propagates
+    double g[W], hh[W], r[W], d[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) hh[w] = __builtin_amdgcn_rsq(x[w]);
+#pragma unroll
+    for (int w = 0; w < W; ++w) g[w] = x[w] * hh[w];
+#pragma unroll
+    for (int w = 0; w < W; ++w) hh[w] = 0.5 * hh[w];
+#pragma unroll
+    for (int w = 0; w < W; ++w) r[w] = fma(-hh[w], g[w], 0.5);
+#pragma unroll
+    for (int w = 0; w < W; ++w) g[w] = fma(g[w], r[w], g[w]);
+#pragma unroll
+    for (int w = 0; w < W; ++w) hh[w] = fma(hh[w], r[w], hh[w]);
+#pragma unroll
+    for (int w = 0; w < W; ++w) d[w] = fma(-g[w], g[w], x[w]);
+#pragma unroll
+    for (int w = 0; w < W; ++w) out[w] = fma(d[w], hh[w], g[w]);
 }
 
-// exp(-t) for t >= 0, ~1 ulp: n = rint(-t log2 e), Cody-Waite reduction with a two-part ln 2,
-// degree-13 Taylor polynomial on |f| <= ln2/2, scale by 2^n (v_ldexp_f64).  t > 745 -> 0.
-__device__ __forceinline__ double exp_neg(double t)
+// exp(-t) for t in [0, 800], ~1 ulp: n = rint(-t log2 e) by the 1.5 * 2^52 shift (its low word
+// is n as an integer), Cody-Waite reduction with a two-part ln 2, degree-13 Taylor polynomial
+// on |f| <= ln2/2, scale by 2^n (v_ldexp_f64 rounds into the denormals and to 0 below them, as
+// exp does).
+template <int W>
+__device__ __forceinline__ void exp_neg(const double (&t)[W], double (&out)[W])
 {
-    const double x = -t;
-    const double n = __builtin_rint(x * 1.4426950408889634074);
-    double f = fma(n, -6.93147180369123816490e-01, x);   // ln2_hi
-    f = fma(n, -1.90821492927058770002e-10, f);           // ln2_lo
-    double p = 1.6059043836821613e-10;                    // 1/13!
-    p = fma(p, f, 2.08767569878681e-09);                  // 1/12!
-    p = fma(p, f, 2.505210838544172e-08);                 // 1/11!
-    p = fma(p, f, 2.755731922398589e-07);                 // 1/10!
-    p = fma(p, f, 2.7557319223985893e-06);                // 1/9!
-    p = fma(p, f, 2.48015873015873e-05);                  // 1/8!
-    p = fma(p, f, 1.984126984126984e-04);                 // 1/7!
-    p = fma(p, f, 1.3888888888888889e-03);                // 1/6!
-    p = fma(p, f, 8.333333333333333e-03);                 // 1/5!
-    p = fma(p, f, 4.1666666666666664e-02);                // 1/4!
-    p = fma(p, f, 1.6666666666666666e-01);                // 1/3!
-    p = fma(p, f, 0.5);
-    p = fma(p, f, 1.0);
-    p = fma(p, f, 1.0);
-    const double r = __builtin_ldexp(p, (int)n);
-    return (t < 745.2) ? r : ((t != t) ? t : 0.0);
+    const double SHIFT = 6755399441055744.0;   // 1.5 * 2^52
+    double sh[W], f[W], p[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) sh[w] = fma(-t[w], 1.4426950408889634074, SHIFT);
+#pragma unroll
+    for (int w = 0; w < W; ++w) f[w] = fma(sh[w] - SHIFT, -6.93147180369123816490e-01, -t[w]);   // ln2_hi
+#pragma unroll
+    for (int w = 0; w < W; ++w) f[w] = fma(sh[w] - SHIFT, -1.90821492927058770002e-10, f[w]);     // ln2_lo
+#pragma unroll
+    for (int w = 0; w < W; ++w) p[w] = fma(1.6059043836821613e-10, f[w], 2.08767569878681e-09);   // 1/13!, 1/12!
+#define SPX_EXP_STEP(C_)                              \
+    _Pragma("unroll") for (int w = 0; w < W; ++w) p[w] = fma(p[w], f[w], C_)
+    SPX_EXP_STEP(2.505210838544172e-08);    // 1/11!
+    SPX_EXP_STEP(2.755731922398589e-07);    // 1/10!
+    SPX_EXP_STEP(2.7557319223985893e-06);   // 1/9!
+    SPX_EXP_STEP(2.48015873015873e-05);     // 1/8!
+    SPX_EXP_STEP(1.984126984126984e-04);    // 1/7!
+    SPX_EXP_STEP(1.3888888888888889e-03);   // 1/6!
+    SPX_EXP_STEP(8.333333333333333e-03);    // 1/5!
+    SPX_EXP_STEP(4.1666666666666664e-02);   // 1/4!
+    SPX_EXP_STEP(1.6666666666666666e-01);   // 1/3!
+    SPX_EXP_STEP(0.5);
+    SPX_EXP_STEP(1.0);
+    SPX_EXP_STEP(1.0);
+#undef SPX_EXP_STEP
+#pragma unroll
+    for (int w = 0; w < W; ++w) out[w] = __builtin_ldexp(p[w], __double2loint(sh[w]));
 }
 
-// Matern-5/2 correlation from the Gram term and the two squared norms, in the
-// reference's operation order (the polynomial and the clamp round as numpy's do; sqrt and
-// exp are ~1 ulp device implementations).
-__device__ __forceinline__ double matern52_corr(double g, double s1, double s2)
+// Matern-5/2 correlation from the Gram term and the two squared norms (gp.py:34-54, :120-127):
+//   r2 = np.maximum(-t, 0) is taken as clamp(-t, 1e-300, 1.28e5): below 1e-300 the result is
+//   exactly 1 either way; above 1.28e5, sqrt5 r > 800 and exp underflows to 0 either way.
+//   The clamps are v_max/v_min, which drop NaN, so non-finite t (NaN or inf inputs, where the
+//   reference yields NaN: np.maximum propagates NaN, and inf * exp(-inf) = NaN) is restored by
+//   the closing fma(t, 0, .) -- 0 for finite t, NaN otherwise.
+//   The polynomial (1 + sqrt5 r) + (5/3) r2 keeps the reference's association; sqrt and exp are
+//   ~1 ulp device implementations.
+template <int W>
+__device__ __forceinline__ void matern52_corr(const double (&g)[W], double s1, const double (&s2)[W],
+                                              double (&out)[W])
 {
 #pragma clang fp contract(off)
-    const double t = (g - s1) - s2;
-    const double nt = -t;
-    double r2 = (nt < 0.0) ? 0.0 : nt;  // np.maximum(., 0): NaN propagates (fmax would drop it)
-    r2 = fabs(r2);
-    const double r = sqrt_nonneg(r2);
-    const double poly = (1.0 + SQRT5 * r) + (5.0 / 3.0) * r2;
-    return poly * exp_neg(SQRT5 * r);
+    double t[W], r2[W], r[W], sr[W], e[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+#pragma unroll
+    for (int w = 0; w < W; ++w) r2[w] = __builtin_fmin(__builtin_fmax(-t[w], 1e-300), 1.28e5);
+    sqrt_pos<W>(r2, r);
+#pragma unroll
+    for (int w = 0; w < W; ++w) sr[w] = SQRT5 * r[w];
+    exp_neg<W>(sr, e);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const double poly = (1.0 + sr[w]) + (5.0 / 3.0) * r2[w];
+        out[w] = fma(t[w], 0.0, poly * e[w]);
+    }
 }
 
-// ---------------------------------------------------------------------------
-// Covariance tile kernel.
-//   A side: observations, pre-scaled  Xs[h][Np][Dp], norms s1[h][Np]
-//   B side: columns, pre-scaled by 2  Cs[h][Mc][Dp], norms s2[h][Mc]
-//   out[h][j][c], row stride ldo.
-// Workgroup = 4 waves, tile = 128 rows (j) x 64 columns (c); wave w owns row
-// sub-tiles {w, w+4} (16 rows each) and all 4 column sub-tiles, so one A
-// fragment feeds 4 MFMAs.  Contraction index mapping: lane group g = lane>>4
-// contributes input dims [g*Q, g*Q+Q), Q = Dp/4, so every lane reads Q
-// consecutive doubles of "its" row (vector loads, no LDS needed: both operand
-// panels are a few KB and live in L1/L2).
-// MODE 0: cross-cov  amp2*k, pad rows -> 0
-// MODE 1: self-cov   amp2*(k + 1e-6 [j==c]) + noise [j==c], pad -> identity
-// MODE 2: cross-mean out[h][c] = exp( sum_j amp2*k[j][c]*alpha[h][j] + mean )
-// ---------------------------------------------------------------------------
 template <int MODE, int QC>
 __global__ __launch_bounds__(256, 2) void k_cov(
     const double* __restrict__ Xs, const double* __restrict__ s1,
@@ -188,6 +215,42 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     // MODE 2 accumulates sum_j k[j][c] alpha[j] for this lane's column(s)
     double colsum[4] = {0.0, 0.0, 0.0, 0.0};
 
+    // Matern epilogue of one 16 x 64 tile on the accumulator layout: row = j0 + g + 4 r,
+    // col = c0 + 16 nt + li
+    auto epilogue = [&](const d4 (&acc)[4], int j0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + g + 4 * r;
+            const double s1v = s1h[j];
+            double av = 0.0;
+            if (MODE == 2) av = alpha[(size_t)h * Np + j];
+            const double amp_j = (j < N) ? amp2 : 0.0;
+            double gv[4], cv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) gv[nt] = acc[nt][r];
+            matern52_corr<4>(gv, s1v, s2v, cv);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int c = c0 + 16 * nt + li;
+                const double corr = cv[nt];
+                if (MODE == 0) {
+                    // pad rows (j >= N) are written as 0 (amp_j = 0); a NaN column stays NaN there,
+                    // which is harmless: that candidate's result is NaN anyway
+                    out[((size_t)h * Np + j) * ldo + c] = amp_j * corr;
+                } else if (MODE == 1) {
+#pragma clang fp contract(off)
+                    const double eye = (j == c) ? 1.0 : 0.0;
+                    double v = amp2 * (corr + 1e-6 * eye) + noise * eye;
+                    if (j >= N || c >= N) v = eye;
+                    out[((size_t)h * Np + j) * ldo + c] = v;
+                } else {
+                    // pad rows have alpha == 0 and finite corr
+                    colsum[nt] += (amp2 * corr) * av;
+                }
+            }
+        }
+    };
+
     // MODE 0/1: a workgroup covers `rows_per_wg` rows (a multiple of 128) so that the prologue
     // (column-side fragment and norm loads, ~1-2 us of latency) is amortised over many row tiles
     const int jbeg = (MODE == 2) ? 0 : blockIdx.y * rows_per_wg;
@@ -214,33 +277,7 @@ __global__ __launch_bounds__(256, 2) void k_cov(
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[nt] = MFMA_F64(af[q], bf[nt][q], acc[nt]);
         }
-        // epilogue on the accumulator layout: row = j0 + g + 4 r, col = c0 + 16 nt + li
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + g + 4 * r;
-            const double s1v = s1h[j];
-            double av = 0.0;
-            if (MODE == 2) av = alpha[(size_t)h * Np + j];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int c = c0 + 16 * nt + li;
-                const double corr = matern52_corr(acc[nt][r], s1v, s2v[nt]);
-                if (MODE == 0) {
-                    double v = amp2 * corr;
-                    if (j >= N) v = 0.0;
-                    out[((size_t)h * Np + j) * ldo + c] = v;
-                } else if (MODE == 1) {
-#pragma clang fp contract(off)
-                    const double eye = (j == c) ? 1.0 : 0.0;
-                    double v = amp2 * (corr + 1e-6 * eye) + noise * eye;
-                    if (j >= N || c >= N) v = eye;
-                    out[((size_t)h * Np + j) * ldo + c] = v;
-                } else {
-                    // pad rows have alpha == 0 and finite corr
-                    colsum[nt] += (amp2 * corr) * av;
-                }
-            }
-        }
+        epilogue(acc, j0);
     }
 
     if (MODE == 2) {
