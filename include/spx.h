@@ -148,6 +148,15 @@ int spx_gp_logprob(spx_handle* h, double* out);
  * factored (spx_set_time_model / spx_ei_per_sec_grid) the objective is EI per second and
  * its gradient (GPEIperSecChooser.py:349-434).                                           */
 int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad /* D */);
+/* Sobol candidate grid on the device (ExperimentGrid.py:192-196 -> sobol_lib.py:125-157
+ * i4_sobol_generate; "next" row 4): grid (n x dim, row-major) = transpose(i4_sobol_generate(dim,
+ * n, skip)), bit-identical to the reference.  dirs = its scaled direction integers V[d][b]
+ * (dim_max x 30 uint32, host; spearmint_amd/data/sobol_dirs_*.npy), dim <= dim_max,
+ * skip + n - 2 < 2^30.  grid_out (host) may be NULL.  as_candidates != 0 also leaves the grid
+ * resident as the candidate set (== spx_set_candidates(grid, n, dim, 0) without the host copy).
+ * kernel_ms (may be NULL) receives the HIP-event duration of the generating kernel.          */
+int spx_sobol_grid(spx_handle* h, const uint32_t* dirs, int32_t dim_max, int32_t dim, int64_t n,
+                   int64_t skip, double* grid_out, int32_t as_candidates, double* kernel_ms);
 /* which draw / pivot failed in the last SPX_ERR_NOT_PD                         */
 int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot);
 

@@ -48,7 +48,7 @@ class GPEIBase(object):
 
     def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
                  noiseless=False, device=0, ndev=1, lib=None, gpu_logprob="auto", gpu_refine="auto",
-                 lookahead=8, **unused):
+                 lookahead=8, gpu_sobol=0, **unused):
         if covar != "Matern52":
             # the HIP path implements the ARD Matern-5/2 kernel named by the north star
             raise ValueError("spearmint_amd choosers support covar=Matern52 only (got %r)" % (covar,))
@@ -68,6 +68,12 @@ class GPEIBase(object):
         # same choice for the EI + gradient objective of the local refinement (spx_ei_grad)
         self.gpu_refine = str(gpu_refine)
         self.lookahead = max(1, int(lookahead))   # slice-sampler proposals evaluated speculatively per GPU call
+        # opt-in: have the driver's ExperimentGrid build its Sobol candidate grid with the HIP
+        # generator (bit-identical; spearmint-lite rebuilds the grid on every invocation)
+        self.gpu_sobol = _as_bool(gpu_sobol)
+        if self.gpu_sobol:
+            from .. import sobol as _sobol
+            _sobol.install(device=self.device, log=log)
         self._lp_key = None
         self.D = -1
         self._eng = None          # created lazily in next(): never before a fork, never pickled

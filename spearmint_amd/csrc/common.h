@@ -63,6 +63,9 @@ void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, con
                          double* out, int N, int Np, int D, int Dp, int nh, const double* kt = nullptr,
                          const double* dkt = nullptr);
 
+// sobol_kernels.hip
+void launch_sobol_grid(hipStream_t s, const uint32_t* dirs, int dim, int64_t n, int64_t skip, double* out);
+
 // predict_kernels.hip
 void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
                          double* part_ss, double* part_bg, int Np, int Mc, int nh,

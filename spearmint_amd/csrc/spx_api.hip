@@ -91,6 +91,7 @@ struct spx_handle {
     int S = 0;
     DevBuf fantT, gammaS, bests, part_bgS[2];
     DevBuf pt_x, pt_k, pt_dk, pt_t, pt_z, pt_out, pt_kt, pt_dkt;   // spx_ei_grad work vectors
+    DevBuf sobol_dirs, sobol_out;                                   // spx_sobol_grid
 
     double best_val = 0.0;
     int64_t best_idx = -1;
@@ -198,7 +199,7 @@ void spx_destroy(spx_handle* h)
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
                           &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
-                          &h->am_out_val, &h->am_out_idx, &h->scratch};
+                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
@@ -770,6 +771,43 @@ int spx_ei_per_sec_grid(spx_handle* h, const double* comp, const double* vals, c
     if (!h || !log_durs || !time_hypers) return fail(SPX_ERR_ARG, "spx_ei_per_sec_grid: null argument");
     return run_grid(h, comp, vals, log_durs, N, D, cand, M, hypers, time_hypers, H, flags | SPX_FLAG_PER_SEC,
                     ei_mean_out, ei_draw_out, best_idx, best_val);
+}
+
+int spx_sobol_grid(spx_handle* h, const uint32_t* dirs, int32_t dim_max, int32_t dim, int64_t n,
+                   int64_t skip, double* grid_out, int32_t as_candidates, double* kernel_ms)
+{
+    if (!h || !dirs || dim < 1 || dim > dim_max || n < 1)
+        return fail(SPX_ERR_ARG, "spx_sobol_grid: bad arguments (dim=%d of %d, n=%lld)", dim, dim_max, (long long)n);
+    if (skip + n - 2 >= (1ll << 30) || skip < -(1ll << 40))
+        return fail(SPX_ERR_ARG, "spx_sobol_grid: skip + n - 2 = %lld does not fit 30 direction columns "
+                    "(the reference stops with 'Too many calls')", (long long)(skip + n - 2));
+    if (as_candidates && h->have_obs && dim != h->D)
+        return fail(SPX_ERR_ARG, "spx_sobol_grid: dim=%d but observations have D=%d", dim, h->D);
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    const size_t tbytes = (size_t)dim * 30 * sizeof(uint32_t);
+    if ((rc = h->sobol_dirs.reserve(tbytes))) return rc;
+    DevBuf& dst = as_candidates ? h->cand : h->sobol_out;
+    if ((rc = dst.reserve((size_t)n * dim * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(h->sobol_dirs.p, dirs, tbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(h->ev_t0, s));
+    launch_sobol_grid(s, (const uint32_t*)h->sobol_dirs.p, dim, n, skip, dst.d());
+    HIPCHK(hipEventRecord(h->ev_t1, s));
+    if (grid_out) HIPCHK(hipMemcpyAsync(grid_out, dst.p, (size_t)n * dim * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (kernel_ms) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+        *kernel_ms = ms;
+    }
+    if (as_candidates) {
+        if (!h->have_obs) { h->D = dim; h->Dp = padded_dim(dim); }
+        h->M = n; h->index_base = 0;
+        h->have_cand = true; h->ran = false;
+    }
+    return SPX_OK;
 }
 
 int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad)

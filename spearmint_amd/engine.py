@@ -61,6 +61,8 @@ ABI = {
     "spx_get_time_mean": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p]),
     "spx_gp_logprob": (ctypes.c_int, [_vp, _c_double_p]),
     "spx_ei_grad": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p]),
+    "spx_sobol_grid": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_int32, _c_double_p]),
     "spx_not_pd_info": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p]),
     "spx_get_timings": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p, ctypes.c_int]),
     "spx_timing_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -309,6 +311,26 @@ class Engine(object):
         g = np.empty(self.D)
         self._check(self._lib.spx_ei_grad(self._h, _dp(x), ctypes.byref(f), _dp(g)))
         return float(f.value), g
+
+    def sobol_grid(self, dirs, dim, n, skip, fetch=True, as_candidates=False):
+        """The reference's Sobol grid, generated on the GPU: returns (grid, kernel_ms) with
+        grid (n, dim) == np.transpose(i4_sobol_generate(dim, n, skip)) bit for bit
+        (ExperimentGrid.py:192-196), or None when fetch is False.  dirs: (dim_max, 30) uint32
+        direction integers (spearmint_amd.sobol.load_dirs).  as_candidates leaves the grid
+        resident as the candidate set."""
+        dirs = np.ascontiguousarray(dirs, dtype=np.uint32)
+        if dirs.ndim != 2 or dirs.shape[1] != 30:
+            raise ValueError("dirs must be (dim_max, 30) uint32")
+        out = np.empty((int(n), int(dim))) if fetch else None
+        ms = ctypes.c_double(0.0)
+        self._check(self._lib.spx_sobol_grid(
+            self._h, dirs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), dirs.shape[0], int(dim), int(n),
+            int(skip), _dp(out) if fetch else None, 1 if as_candidates else 0, ctypes.byref(ms)))
+        if as_candidates:
+            self.M = int(n)
+            if not self.D:
+                self.D = int(dim)
+        return out, float(ms.value)
 
     def not_pd_info(self):
         d = ctypes.c_int32(-1); p = ctypes.c_int32(-1)
