@@ -70,6 +70,11 @@ class OracleEngine(object):
         self.calls.append(("ei_grid", cand.shape[0], np.atleast_2d(hypers).shape[0]))
         return idx, float(mean[idx]), mean, (ei if want_draws else None)
 
+    def sobol_grid(self, dirs, dim, n, skip, fetch=True, as_candidates=False):
+        from oracle import sobol_oracle
+        self.calls.append(("sobol_grid", int(dim), int(n), int(skip)))
+        return np.ascontiguousarray(sobol_oracle.i4_sobol_generate(dim, n, skip, dirs).T), 0.0
+
     def ei_grad(self, x):
         from spearmint_amd import hostgp
         total, grad = 0.0, np.zeros(len(x))

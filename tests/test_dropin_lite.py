@@ -92,3 +92,47 @@ def test_unmodified_lite_loop_drives_our_chooser(lite, method, margs):
     if method == "GPEIOptChooser":
         assert os.path.exists(os.path.join(expt, "chooser.GPEIOptChooser.pkl"))
         assert os.path.exists(os.path.join(expt, "chooser.GPEIOptChooser_hyperparameters.txt"))
+
+
+def test_gpu_sobol_option_rebinds_the_grid_generator(lite, monkeypatch):
+    """--method-args gpu_sobol=1: spearmint-lite's ExperimentGrid builds its candidate grid with
+    our generator (here the test-only oracle engine stands in for the GPU), and the proposals are
+    the ones the reference's own pure-Python generator leads to."""
+    mod, work = lite
+    from spearmint_amd import sobol as ssob
+    from tests.helpers import OracleEngine
+    fake = OracleEngine()
+    monkeypatch.setattr(ssob, "_engine", fake)
+    expt = os.path.join(str(work), "braninpy")
+    res = os.path.join(expt, "results.dat")
+
+    def run(margs):
+        open(res, "w").close()
+        for f in os.listdir(expt):
+            if f.endswith(".pkl"):
+                os.remove(os.path.join(expt, f))
+        opts = types.SimpleNamespace(num_jobs=1, max_finished_jobs=1000, chooser_module="GPEIChooser",
+                                     chooser_args=margs, grid_size=150, grid_seed=1,
+                                     config_file="config.json", results_file="results.dat")
+        np.random.seed(11)
+        out = []
+        for it in range(4):
+            mod.main_controller(opts, [expt])
+            lines = open(res).read().strip().split("\n")
+            out.append(lines[-1])
+            x = [float(v) for v in lines[-1].split()[2:]]
+            lines[-1] = "%f 1.5 %s" % (_branin(x), " ".join(lines[-1].split()[2:]))
+            open(res, "w").write("\n".join(lines) + "\n")
+        return out
+
+    try:
+        plain = run("mcmc_iters=2")
+        assert not any(c[0] == "sobol_grid" for c in fake.calls)
+        patched = run("mcmc_iters=2,gpu_sobol=1")
+        gen = [c for c in fake.calls if c[0] == "sobol_grid"]
+        assert gen[0] == ("sobol_grid", 40, 16, 3)          # the table-identification probe
+        assert len(gen) >= 5 and all(c[1] == 2 and c[2] == 150 for c in gen[1:])
+        assert patched == plain
+        assert getattr(sys.modules["ExperimentGrid"].i4_sobol_generate, "_spx_gpu", False)
+    finally:
+        ssob.uninstall()
