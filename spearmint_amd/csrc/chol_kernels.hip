@@ -101,18 +101,12 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             acc[nt][r] = Lh[(kb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
+    // steps p < k-1 were already applied in place by the previous panel launch (k_chol_panel,
+    // diag_pre); only p = k-1, whose tile that launch produced, is left
     if (k > 0) {
-        // one barrier per step: step p's tile is written to buffer p&1 while nobody can still be
-        // reading it (every wave finished step p-2's MFMAs before the barrier of step p-1)
-        TileRegs tr;
-        tile_load(Lh + kb0 * Np, Np, tr);
-        for (int p = 0; p < k; ++p) {
-            double* Pc = P + (p & 1) * NB * LDP;
-            tile_store(tr, Pc);
-            __syncthreads();
-            if (p + 1 < k) tile_load(Lh + kb0 * Np + (size_t)(p + 1) * NB, Np, tr);
-            mma_tile_64(Pc, Pc, acc, wave, g, li, true);
-        }
+        tile_to_lds(Lh + kb0 * Np + (size_t)(k - 1) * NB, Np, P);
+        __syncthreads();
+        mma_tile_64(P, P, acc, wave, g, li, true);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -254,8 +248,13 @@ void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np,
 }
 
 // ---------------------------------------------------------------------------
+// With pre != 0, workgroup x = 0 of every draw does not compute a panel tile: it applies the
+// first k steps of the NEXT diagonal block's update, K_{k+1,k+1} -= sum_{p<k} L_{k+1,p} L_{k+1,p}^T
+// (in place; those tiles are final), so that k_chol_diag(k+1) -- alone on the chip, the critical
+// path of the factorisation -- is left with the single step p = k instead of k + 1 steps.  Same
+// accumulation order as before, so the factor is bit-identical.
 __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
-                                                    const double* __restrict__ Dinv, int Np, int k)
+                                                    const double* __restrict__ Dinv, int Np, int k, int pre)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;                  // [2][64][LDP]
@@ -264,9 +263,12 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
     const int g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
     const int nblk = Np / NB;
-    const int rb = k + 1 + blockIdx.x;
+    const bool diag_pre = pre && blockIdx.x == 0;
+    const int rb = k + 1 + (int)blockIdx.x - (pre && !diag_pre ? 1 : 0);
     double* Lh = Lm + (size_t)h * Np * Np;
-    const size_t kb0 = (size_t)k * NB, rb0 = (size_t)rb * NB;
+    const size_t rb0 = (size_t)rb * NB;
+    // the other operand's rows (and this tile's columns): block row k, or rb itself for diag_pre
+    const size_t kb0 = diag_pre ? rb0 : (size_t)k * NB;
 
     d4 acc[4];
 #pragma unroll
@@ -290,6 +292,14 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
             }
             mma_tile_64(Ac, Bc, acc, wave, g, li, true);
         }
+    }
+    if (diag_pre) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Lh[(rb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li] = acc[nt][r];
+        return;
     }
     __syncthreads();
     // L_rk = S L_kk^-T :  out[i][n] = sum_q S[i][q] Dinv[n][q]
@@ -316,7 +326,8 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
     const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);                // 135 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_panel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k - 1, nh), dim3(256), lds, s, L, Dinv, Np, k);
+    const int pre = (k > 0) ? 1 : 0;   // k = 0: the next diagonal block has no earlier steps
+    hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k - 1 + pre, nh), dim3(256), lds, s, L, Dinv, Np, k, pre);
 }
 
 // ---------------------------------------------------------------------------
@@ -330,17 +341,21 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
                                                const double* __restrict__ Dinv,
-                                               double* __restrict__ WT, int Np)
+                                               double* __restrict__ WT, int Np, int nh)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;                  // [2][64][LDP]
     double* B = smem + 2 * NB * LDP;   // [2][64][LDP]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.y;
     const int nblk = Np / NB;
-    // heavy block columns (small jb) first
-    const int jb = blockIdx.x;
+    // Block column jb costs (nblk-jb)(nblk-jb-1)/2 tile steps.  Workgroups are numbered column-major
+    // over (draw, column): all draws' column 0 first, then column 1, ... -- longest first for the
+    // dispatcher, and consecutive ids (which land on consecutive XCDs) carry equal work.  With a
+    // (column, draw) grid the id modulo 8 was the column modulo 8, so one XCD got every draw's
+    // heaviest column: 4.7 ms instead of 1.5 ms at N=2048, H=20.
+    const int jb = blockIdx.x / nh;
+    const int h = blockIdx.x - jb * nh;
     const double* Lh = Lm + (size_t)h * Np * Np;
     double* Wh = WT + (size_t)h * Np * Np;
     const double* Dh = Dinv + (size_t)h * nblk * NB * NB;
@@ -398,7 +413,7 @@ void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT
     const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trinv),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_trinv, dim3(Np / NB, nh), dim3(256), lds, s, L, Dinv, WT, Np);
+    hipLaunchKernelGGL(k_trinv, dim3((Np / NB) * nh), dim3(256), lds, s, L, Dinv, WT, Np, nh);
 }
 
 // ---------------------------------------------------------------------------
