@@ -253,8 +253,14 @@ void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np,
 // (in place; those tiles are final), so that k_chol_diag(k+1) -- alone on the chip, the critical
 // path of the factorisation -- is left with the single step p = k instead of k + 1 steps.  Same
 // accumulation order as before, so the factor is bit-identical.
+// With rhs != null, the last workgroup x of every draw carries the right-hand side along: rhs is
+// a [nh][64][Np] buffer whose row 0 holds r^T = (vals - mean)^T (rows 1..63 zero), treated as one
+// more row block below the matrix -- the Cholesky of [[K, r], [r^T, .]] has y^T = (L^-1 r)^T in
+// that row.  The forward solve of the log-likelihood then costs no extra pass over L and no
+// latency of its own (it ran 2.4 ms as a separate sequential kernel at N=2048).
 __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
-                                                    const double* __restrict__ Dinv, int Np, int k, int pre)
+                                                    const double* __restrict__ Dinv, int Np, int k, int pre,
+                                                    double* __restrict__ rhs)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;                  // [2][64][LDP]
@@ -264,9 +270,12 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
     const int h = blockIdx.y;
     const int nblk = Np / NB;
     const bool diag_pre = pre && blockIdx.x == 0;
+    const bool is_rhs = rhs && blockIdx.x == gridDim.x - 1;
     const int rb = k + 1 + (int)blockIdx.x - (pre && !diag_pre ? 1 : 0);
     double* Lh = Lm + (size_t)h * Np * Np;
     const size_t rb0 = (size_t)rb * NB;
+    // this tile's 64 rows: block row rb of the matrix, or the right-hand-side rows
+    double* Ar = is_rhs ? rhs + (size_t)h * NB * Np : Lh + rb0 * Np;
     // the other operand's rows (and this tile's columns): block row k, or rb itself for diag_pre
     const size_t kb0 = diag_pre ? rb0 : (size_t)k * NB;
 
@@ -275,10 +284,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            acc[nt][r] = Lh[(rb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
+            acc[nt][r] = Ar[(size_t)(16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
     if (k > 0) {
         TileRegs ta, tb;
-        tile_load(Lh + rb0 * Np, Np, ta);
+        tile_load(Ar, Np, ta);
         tile_load(Lh + kb0 * Np, Np, tb);
         for (int p = 0; p < k; ++p) {
             double* Ac = A + (p & 1) * NB * LDP;
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
             tile_store(tb, Bc);
             __syncthreads();
             if (p + 1 < k) {
-                tile_load(Lh + rb0 * Np + (size_t)(p + 1) * NB, Np, ta);
+                tile_load(Ar + (size_t)(p + 1) * NB, Np, ta);
                 tile_load(Lh + kb0 * Np + (size_t)(p + 1) * NB, Np, tb);
             }
             mma_tile_64(Ac, Bc, acc, wave, g, li, true);
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                Lh[(rb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li] = acc[nt][r];
+                Ar[(size_t)(16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li] = acc[nt][r];
         return;
     }
     __syncthreads();
@@ -316,18 +325,20 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            Lh[(rb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li] = acc[nt][r];
+            Ar[(size_t)(16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li] = acc[nt][r];
 }
 
-void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh)
+void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs)
 {
     const int nblk = Np / NB;
-    if (nblk - k - 1 <= 0) return;
+    const int nrows = nblk - k - 1;
+    const int pre = (k > 0 && nrows > 0) ? 1 : 0;   // k = 0: the next diagonal block has no earlier steps
+    const int nx = nrows + pre + (rhs ? 1 : 0);
+    if (nx <= 0) return;
     const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);                // 135 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_panel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int pre = (k > 0) ? 1 : 0;   // k = 0: the next diagonal block has no earlier steps
-    hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k - 1 + pre, nh), dim3(256), lds, s, L, Dinv, Np, k, pre);
+    hipLaunchKernelGGL(k_chol_panel, dim3(nx, nh), dim3(256), lds, s, L, Dinv, Np, k, pre, rhs);
 }
 
 // ---------------------------------------------------------------------------
@@ -491,76 +502,38 @@ void launch_alpha(hipStream_t s, const double* WT, const double* gamma, double* 
     hipLaunchKernelGGL(k_alpha, dim3(Np / 4, nh), dim3(256), 0, s, WT, gamma, alpha, Np);
 }
 
-// ---------------------------------------------------------------------------
-// gamma = L^-1 (vals - mean) by blocked forward substitution, one workgroup per draw:
-//   gamma_k = Dinv_k ( r_k - sum_{p<k} L_kp gamma_p )
-// Used by the lean log-likelihood path (no W = L^-1 needed).  Wave w owns rows
-// 16 w .. 16 w + 15 of the block row; lanes run along the columns (coalesced 512 B
-// row segments) and a shuffle tree reduces each row.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwd_solve(const double* __restrict__ Lm,
-                                                   const double* __restrict__ Dinv,
-                                                   const double* __restrict__ vals,
-                                                   const double* __restrict__ htab,
-                                                   double* __restrict__ gamma, int N, int Np)
+// rhs[h][0][j] = vals[j] - mean_h (0 for pad entries), rows 1..63 = 0: the right-hand-side row
+// block that k_chol_panel carries through the factorisation (log-likelihood path)
+__global__ __launch_bounds__(256) void k_rhs_init(const double* __restrict__ vals,
+                                                  const double* __restrict__ htab,
+                                                  double* __restrict__ rhs, int N, int Np)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* gam = smem;        // [Np]
-    double* tvec = smem + Np;  // [64]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = blockIdx.x;
-    const int nblk = Np / NB;
-    const double* Lh = Lm + (size_t)h * Np * Np;
-    const double* Dh = Dinv + (size_t)h * nblk * NB * NB;
-    const double mean = htab[h * SPX_HT + 0];
-    for (int k = 0; k < nblk; ++k) {
-        const size_t kb0 = (size_t)k * NB;
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = 16 * wave + rr;
-            const double* Lr = Lh + (kb0 + row) * Np;
-            double acc = 0.0;
-            for (int cidx = lane; cidx < (int)kb0; cidx += 64) acc += Lr[cidx] * gam[cidx];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-            if (lane == 0) {
-                const int gi = (int)kb0 + row;
-                const double r = (gi < N) ? (vals[gi] - mean) : 0.0;
-                tvec[row] = r - acc;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < NB) {
-            const double* Dr = Dh + (size_t)k * NB * NB + threadIdx.x * NB;
-            double acc = 0.0;
-            for (int q = 0; q <= (int)threadIdx.x; ++q) acc += Dr[q] * tvec[q];
-            gam[kb0 + threadIdx.x] = acc;
-            gamma[(size_t)h * Np + kb0 + threadIdx.x] = acc;
-        }
-        __syncthreads();
-    }
+    const int h = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;      // over [64][Np]
+    if (idx >= NB * Np) return;
+    const int row = idx / Np, j = idx - row * Np;
+    double v = 0.0;
+    if (row == 0 && j < N) v = vals[j] - htab[h * SPX_HT + 0];
+    rhs[(size_t)h * NB * Np + idx] = v;
 }
 
-void launch_fwd_solve(hipStream_t s, const double* L, const double* Dinv, const double* vals,
-                      const double* htab, double* gamma, int N, int Np, int nh)
+void launch_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh)
 {
-    const size_t lds = (size_t)(Np + NB) * sizeof(double);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_solve),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_fwd_solve, dim3(nh), dim3(256), lds, s, L, Dinv, vals, htab, gamma, N, Np);
+    hipLaunchKernelGGL(k_rhs_init, dim3((NB * Np + 255) / 256, nh), dim3(256), 0, s, vals, htab, rhs, N, Np);
 }
 
 // lp = -sum log diag(L) - 0.5 |gamma|^2   (GPEIChooser.py:284); -inf if not PD
 __global__ __launch_bounds__(256) void k_logprob(const double* __restrict__ Lm,
                                                  const double* __restrict__ gamma,
                                                  const int* __restrict__ info,
-                                                 double* __restrict__ out, int N, int Np)
+                                                 double* __restrict__ out, int N, int Np, size_t gstride)
 {
     __shared__ double red[2][256];
     const int h = blockIdx.x;
     double sl = 0.0, sq = 0.0;
     for (int i = threadIdx.x; i < N; i += 256) {
         sl += log(Lm[((size_t)h * Np + i) * Np + i]);
-        const double gi = gamma[(size_t)h * Np + i];
+        const double gi = gamma[(size_t)h * gstride + i];
         sq += gi * gi;
     }
     red[0][threadIdx.x] = sl;
@@ -577,9 +550,9 @@ __global__ __launch_bounds__(256) void k_logprob(const double* __restrict__ Lm,
         out[h] = info[h] ? -__builtin_inf() : (-red[0][0] - 0.5 * red[1][0]);
 }
 
-void launch_logprob(hipStream_t s, const double* L, const double* gamma, const int* info,
+void launch_logprob(hipStream_t s, const double* L, const double* gamma, size_t gstride, const int* info,
                     double* out, int Np, int nh)
 {
     // N is recovered on the host side: pad rows have L_ii = 1 (log 0) and gamma = 0
-    hipLaunchKernelGGL(k_logprob, dim3(nh), dim3(256), 0, s, L, gamma, info, out, Np, Np);
+    hipLaunchKernelGGL(k_logprob, dim3(nh), dim3(256), 0, s, L, gamma, info, out, Np, Np, gstride);
 }

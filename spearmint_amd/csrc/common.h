@@ -40,7 +40,7 @@ void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const 
 
 // chol_kernels.hip
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh);
-void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh);
+void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs = nullptr);
 void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh);
 void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
                   double* gamma, int N, int Np, int nh);
@@ -48,9 +48,8 @@ void launch_gamma_multi(hipStream_t s, const double* WT_h, const double* rhs, co
                         double* gamma, int N, int Np, int S);
 void launch_gemv_lower(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh);
 void launch_alpha(hipStream_t s, const double* WT, const double* gamma, double* alpha, int Np, int nh);
-void launch_fwd_solve(hipStream_t s, const double* L, const double* Dinv, const double* vals,
-                      const double* htab, double* gamma, int N, int Np, int nh);
-void launch_logprob(hipStream_t s, const double* L, const double* gamma, const int* info,
+void launch_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh);
+void launch_logprob(hipStream_t s, const double* L, const double* gamma, size_t gstride, const int* info,
                     double* out, int Np, int nh);
 
 // refine_kernels.hip

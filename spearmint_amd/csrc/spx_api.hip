@@ -92,6 +92,7 @@ struct spx_handle {
     DevBuf fantT, gammaS, bests, part_bgS[2];
     DevBuf pt_x, pt_k, pt_dk, pt_t, pt_z, pt_out, pt_kt, pt_dkt;   // spx_ei_grad work vectors
     DevBuf sobol_dirs, sobol_out;                                   // spx_sobol_grid
+    DevBuf rhs;                                                     // spx_gp_logprob: [H][64][Np] right-hand-side rows
 
     double best_val = 0.0;
     int64_t best_idx = -1;
@@ -199,7 +200,7 @@ void spx_destroy(spx_handle* h)
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
                           &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
-                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out};
+                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
@@ -356,13 +357,19 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     // second operand pre-multiplied by 2 (gp.py:50); the row norms it writes are identical
     TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 2.0, h->X2s.d(), h->s1.d()));
     TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh));
+    // lean: the right-hand side vals - mean rides through the factorisation as an extra row block
+    // (k_chol_panel, rhs), so y = L^-1 (vals - mean) is ready when the last column is
+    double* rhs = nullptr;
+    if (lean) {
+        if ((rc = h->rhs.reserve((size_t)nh * SPX_NB * Np * 8))) return rc;
+        rhs = h->rhs.d();
+        TIMED(ST_GAMMA_ALPHA, launch_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh));
+    }
     for (int k = 0; k < nblk; ++k) {
         TIMED(ST_CHOL_DIAG, launch_chol_diag(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, Np, k, nh));
-        if (k + 1 < nblk) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh));
+        if (k + 1 < nblk || rhs) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh, rhs));
     }
-    if (lean) {
-        TIMED(ST_GAMMA_ALPHA, launch_fwd_solve(s, h->Lm.d(), h->Dinv.d(), h->vals.d(), h->htab.d(), h->gamma.d(), (int)N, Np, H));
-    } else {
+    if (!lean) {
         TIMED(ST_TRINV, launch_trinv(s, h->Lm.d(), h->Dinv.d(), h->WT.d(), Np, nh));
         TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d(), h->vals.d(), h->htab.d(), h->gamma.d(), (int)N, Np, H));
         if (nm == 2)
@@ -730,7 +737,7 @@ int spx_gp_logprob(spx_handle* h, double* out)
     int rc = do_factor(h, true, true);   // K(X,X), Cholesky, forward solve -- no inverse
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
-    launch_logprob(h->stream, h->Lm.d(), h->gamma.d(), (const int*)h->info.p, h->lp.d(), h->Np, h->H);
+    launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);
     HIPCHK(hipMemcpyAsync(out, h->lp.p, (size_t)h->H * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SPX_OK;
