@@ -80,7 +80,7 @@ __device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, double* __restrict__ Dinv,
-                                                   int* __restrict__ info, int Np, int k)
+                                                   int* __restrict__ info, int Np, int k, int updated)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* P = smem;                  // [2][64][LDP] staging tiles of the row panel (double-buffered)
@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
         for (int r = 0; r < 4; ++r)
             acc[nt][r] = Lh[(kb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
     // steps p < k-1 were already applied in place by the previous panel launch (k_chol_panel,
-    // diag_pre); only p = k-1, whose tile that launch produced, is left
-    if (k > 0) {
+    // diag_pre); only p = k-1, whose tile that launch produced, is left.  In right-looking mode
+    // (k_chol_update) the block arrives fully updated.
+    if (k > 0 && !updated) {
         tile_to_lds(Lh + kb0 * Np + (size_t)(k - 1) * NB, Np, P);
         __syncthreads();
         mma_tile_64(P, P, acc, wave, g, li, true);
@@ -135,8 +136,14 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
                     if (!bad) bad = (int)kb0 + b0 + j + 1;
                     d = 1.0;
                 }
-                const double sd = sqrt(d);
-                const double rinv = 1.0 / sd;
+                // 1/sqrt(d) and sqrt(d) to ~1 ulp from v_rsq_f64 + Newton steps: this pair sits on the
+                // critical path of every pivot, and the library sqrt + division cost ~50 dependent
+                // instructions where these take 9
+                const double y0 = __builtin_amdgcn_rsq(d);
+                const double e0 = fma(-d * y0, y0, 1.0);
+                const double rinv = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+                double sd = d * rinv;
+                sd = fma(fma(-sd, sd, d), 0.5 * rinv, sd);
                 rinvs[j] = rinv;
                 double lij = 0.0;
                 if (i > j) lij = a[j] * rinv;
@@ -239,12 +246,12 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
     }
 }
 
-void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh)
+void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh, int updated)
 {
     const size_t lds = (size_t)(4 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 144 KB > the 64 KB default
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k);
+    hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k, updated);
 }
 
 // ---------------------------------------------------------------------------
@@ -260,7 +267,7 @@ void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np,
 // latency of its own (it ran 2.4 ms as a separate sequential kernel at N=2048).
 __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
                                                     const double* __restrict__ Dinv, int Np, int k, int pre,
-                                                    double* __restrict__ rhs)
+                                                    double* __restrict__ rhs, int nsteps)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;                  // [2][64][LDP]
@@ -285,17 +292,17 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             acc[nt][r] = Ar[(size_t)(16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
-    if (k > 0) {
+    if (nsteps > 0) {   // = k (left-looking); 0 when the tile arrives fully updated (right-looking)
         TileRegs ta, tb;
         tile_load(Ar, Np, ta);
         tile_load(Lh + kb0 * Np, Np, tb);
-        for (int p = 0; p < k; ++p) {
+        for (int p = 0; p < nsteps; ++p) {
             double* Ac = A + (p & 1) * NB * LDP;
             double* Bc = B + (p & 1) * NB * LDP;
             tile_store(ta, Ac);
             tile_store(tb, Bc);
             __syncthreads();
-            if (p + 1 < k) {
+            if (p + 1 < nsteps) {
                 tile_load(Ar + (size_t)(p + 1) * NB, Np, ta);
                 tile_load(Lh + kb0 * Np + (size_t)(p + 1) * NB, Np, tb);
             }
@@ -328,17 +335,68 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
             Ar[(size_t)(16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li] = acc[nt][r];
 }
 
-void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs)
+void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs,
+                       int right_looking)
 {
     const int nblk = Np / NB;
     const int nrows = nblk - k - 1;
-    const int pre = (k > 0 && nrows > 0) ? 1 : 0;   // k = 0: the next diagonal block has no earlier steps
+    // k = 0: the next diagonal block has no earlier steps; right-looking: nothing is deferred
+    const int pre = (k > 0 && nrows > 0 && !right_looking) ? 1 : 0;
     const int nx = nrows + pre + (rhs ? 1 : 0);
     if (nx <= 0) return;
     const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);                // 135 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_panel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_chol_panel, dim3(nx, nh), dim3(256), lds, s, L, Dinv, Np, k, pre, rhs);
+    hipLaunchKernelGGL(k_chol_panel, dim3(nx, nh), dim3(256), lds, s, L, Dinv, Np, k, pre, rhs,
+                       right_looking ? 0 : k);
+}
+
+// ---------------------------------------------------------------------------
+// k_chol_update: right-looking trailing update after block column k,
+//   A_ij -= L_ik L_jk^T   for every lower tile k < j <= i   (and the right-hand-side rows),
+// one 64-deep MFMA step per tile, in place.  Used by the log-likelihood path, where a handful of
+// draws cannot fill the chip with the left-looking panel (a tile's k steps run sequentially in
+// one workgroup: 1.8 ms of critical path at N=2048); here every launch is one step deep.  The
+// steps reach each tile in the same order p = 0, 1, ... as in the left-looking kernel, so the
+// factor is bit-identical.
+__global__ __launch_bounds__(256, 2) void k_chol_update(double* __restrict__ Lm, double* __restrict__ rhs,
+                                                     int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;              // [64][LDP]  L_ik (or the right-hand-side rows' block k)
+    double* B = smem + NB * LDP;   // [64][LDP]  L_jk
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.z;
+    const bool is_rhs = rhs && blockIdx.x == gridDim.x - 1;
+    const int i = k + 1 + blockIdx.x, j = k + 1 + blockIdx.y;
+    if (!is_rhs && j > i) return;
+    double* Lh = Lm + (size_t)h * Np * Np;
+    double* Ar = is_rhs ? rhs + (size_t)h * NB * Np : Lh + (size_t)i * NB * Np;
+    const size_t kb0 = (size_t)k * NB, jb0 = (size_t)j * NB;
+    d4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nt][r] = Ar[(size_t)(16 * wave + g + 4 * r) * Np + jb0 + 16 * nt + li];
+    tile_to_lds(Ar + kb0, Np, A);
+    tile_to_lds(Lh + jb0 * Np + kb0, Np, B);
+    __syncthreads();
+    mma_tile_64(A, B, acc, wave, g, li, true);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ar[(size_t)(16 * wave + g + 4 * r) * Np + jb0 + 16 * nt + li] = acc[nt][r];
+}
+
+void launch_chol_update(hipStream_t s, double* L, double* rhs, int Np, int k, int nh)
+{
+    const int n = Np / NB - k - 1;
+    if (n <= 0) return;
+    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);   // 67.6 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_update),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_chol_update, dim3(n + (rhs ? 1 : 0), n, nh), dim3(256), lds, s, L, rhs, Np, k);
 }
 
 // ---------------------------------------------------------------------------
