@@ -48,7 +48,7 @@ class GPEIBase(object):
 
     def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
                  noiseless=False, device=0, ndev=1, lib=None, gpu_logprob="auto", gpu_refine="auto",
-                 lookahead=8, gpu_sobol=0, **unused):
+                 lookahead=6, gpu_sobol=0, **unused):
         if covar != "Matern52":
             # the HIP path implements the ARD Matern-5/2 kernel named by the north star
             raise ValueError("spearmint_amd choosers support covar=Matern52 only (got %r)" % (covar,))
