@@ -342,6 +342,25 @@ def test_gpu_loglikelihood_large_n_and_not_pd(eng):
         eng.ei_run()
 
 
+def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
+    """Up to 32 draws the log-likelihood path factors right-looking, beyond that left-looking with
+    the right-hand side as an extra row block; both apply a tile's updates in the same order, so a
+    draw's value must not depend on how many others share the batch (the speculative slice
+    sampler relies on that)."""
+    comp, cand, vals, hypers = synthetic_problem(330, 10, 5, 40, 37)
+    hypers[7, 2] = -1.0                                  # one non-PD draw in the batch
+    eng.set_observations(comp, vals)
+    eng.set_hypers(hypers)
+    big = eng.gp_logprob()                               # 40 draws: left-looking
+    assert big[7] == -np.inf and np.all(np.isfinite(np.delete(big, 7)))
+    for lo, hi in ((0, 1), (1, 6), (6, 38), (20, 40)):   # 1, 5, 32 and 20 draws: right-looking
+        eng.set_hypers(hypers[lo:hi])
+        assert np.array_equal(eng.gp_logprob(), big[lo:hi])
+    for h in (0, 19, 39):
+        ref = orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:])
+        assert np.isclose(big[h], ref, rtol=1e-11)
+
+
 # ---- pending experiments ("next" row 2): fantasies on the GPU --------------------------
 def test_golden_pending_fantasies(eng, golden_dir):
     from spearmint_amd import hostgp
