@@ -11,7 +11,7 @@
 #include "../../include/spx.h"
 #include "common.h"
 
-#define SPX_VERSION 100
+#define SPX_VERSION 101
 
 static thread_local std::string g_err;
 
