@@ -32,7 +32,8 @@
 // STG = how the operand tiles reach LDS: 0 registers + ds_write (prefetch distance one tile),
 //       1 LDS-DMA (global_load_lds, no staging registers, no ds_write).
 // ABL > 0: timing-only ablations for performance analysis (wrong results): 1 = no in-loop
-// global loads / LDS stores, 2 = also no barriers, 3 = also operand fragments read once.
+// global loads / LDS stores, 2 = also no barriers, 3 = also operand fragments read once,
+// 4 (with STG 1) = every DMA fetches the first tile again (cache-resident loads).
 template <int NW, int STG, int ABL>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     const double* __restrict__ WT, const double* __restrict__ Kst,
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     // instruction.  Wave w moves rows w, w + NW, ... of both operand tiles.
 #define SPX_DMA_TILE(KT_, BUF_)                                                                            \
     {                                                                                                      \
-        const size_t j0_ = (size_t)(KT_) * BK;                                                             \
+        const size_t j0_ = (ABL == 4) ? 0 : (size_t)(KT_) * BK;   /* ABL 4: always the first tile */       \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
             const int row = wave + NW * q;                                                                 \
             __builtin_amdgcn_global_load_lds(Ag + (j0_ + row) * Np + 2 * lane,                             \
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
 
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (STG == 1 && ABL == 0 && kt + 1 < nk) SPX_DMA_TILE(kt + 1, cur ^ 1)
+        if (STG == 1 && (ABL == 0 || ABL == 4) && kt + 1 < nk) SPX_DMA_TILE(kt + 1, cur ^ 1)
         const bool more = (STG == 0) && (ABL == 0) && (kt + 1 < nk);
         if (more) {
             const size_t j0 = (size_t)(kt + 1) * BK;
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
             }
         }
         if (STG == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA rows have landed
-        if (ABL < 2) __syncthreads();
-        if (ABL == 0) cur ^= 1;
+        if (ABL < 2 || ABL == 4) __syncthreads();
+        if (ABL == 0 || ABL == 4) cur ^= 1;
     }
 #undef SPX_DMA_TILE
 
@@ -327,6 +328,7 @@ void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, con
         case 41: SPX_GO(4, 0, 1); break;
         case 42: SPX_GO(4, 0, 2); break;
         case 43: SPX_GO(4, 0, 3); break;
+        case 44: SPX_GO(4, 1, 4); break;
         case 4:  SPX_GO(4, 0, 0); break;
         default: SPX_GO(4, 1, 0); break;   // production: 4 waves, LDS-DMA staging (measured fastest)
     }
