@@ -275,6 +275,10 @@ def test_c3_full_size_properties(eng):
     i2, _, _, d2 = eng.ei_grid(comp, vals, cand[sub], hypers, want_draws=True)
     assert np.array_equal(d2, draws[sub])
     assert sub[i2] == idx or mean[sub[i2]] == mean[idx]
+    # (4) a 20 000-candidate subsample for the first and last draw: ~7 s of oracle time
+    big = np.random.RandomState(1).choice(M, 20000, replace=False)
+    for hd in (0, H - 1):
+        assert_ei_close(draws[big, hd], orc.compute_ei(comp, cand[big], vals, hypers[hd]), rtol=1e-6)
 
 
 # ---- the plugin API end to end on the GPU --------------------------------------------
