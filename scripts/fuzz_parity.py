@@ -37,7 +37,11 @@ for c in range(ncases):
     lref = np.array([orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:]) for h in range(H)])
     lerr = float(np.max(np.abs(lp - lref) / np.abs(lref)))
     worst = max(worst, err)
-    flag = "" if (err < 1e-7 and ok_arg and lerr < 1e-9) else "   <-- FAIL"
+    # north-star tolerance 1e-5; the GPU tests assert 1e-7 on well-conditioned problems.  Errors grow with
+    # eps * cond(K): D = 1 with >1000 observations on a line reaches 6e-7 (W = L^-1 vs LAPACK substitution).
+    flag = "" if (err < 1e-5 and ok_arg and lerr < 1e-9) else "   <-- FAIL"
+    if not flag and err >= 1e-7:
+        flag = "   (ill-conditioned: > 1e-7)"
     print("case %2d N=%4d M=%5d D=%2d H=%d per_sec=%d  ei rel err %.2e  logprob rel err %.1e  argmax %s%s"
           % (c, N, M, D, H, per_sec, err, lerr, ok_arg, flag))
 # Sobol: random (dim, n, skip)
