@@ -175,22 +175,39 @@ class GPEIBase(object):
         """Adapter for util.slice_sample_batched: `to_row(x)` gives the hyper row to evaluate or
         None when x is rejected a priori (-inf without touching the GP, as the reference's
         closures do); `finish(x, data_lp)` adds the priors."""
+        # Data terms of the previous batch, keyed by the hyper row's bytes: every slice move starts by
+        # re-evaluating the point the previous move accepted (util.py:46), which that batch already
+        # holds -- the value is a deterministic function of the row, so it is reused, not recomputed.
+        memo = {}
+
         def many(xs):
-            rows, where = [], []
+            rows, where, keys = [], [], []
+            got = {}
             for k, x in enumerate(xs):
                 r = to_row(x)
                 if r is not None:
-                    rows.append(r)
-                    where.append(k)
+                    key = np.asarray(r, dtype=float).tobytes()
+                    if key in memo:
+                        got[k] = memo[key]
+                    else:
+                        rows.append(r)
+                        where.append(k)
+                        keys.append(key)
             values = [-np.inf] * len(xs)
             errors = [None] * len(xs)
+            fresh = {}
             if rows:
                 lp, bad = self.data_logprob_many(comp, vals, np.array(rows))
                 for j, k in enumerate(where):
-                    if bad[j]:   # spla.cholesky would raise here -- only if the sampler really gets to it
-                        errors[k] = np.linalg.LinAlgError("covariance not positive definite")
-                    else:
-                        values[k] = finish(xs[k], lp[j])
+                    fresh[keys[j]] = got[k] = (lp[j], bool(bad[j]))
+            for k, (lpk, badk) in got.items():
+                if badk:   # spla.cholesky would raise here -- only if the sampler really gets to it
+                    errors[k] = np.linalg.LinAlgError("covariance not positive definite")
+                else:
+                    values[k] = finish(xs[k], lpk)
+            if fresh:
+                memo.clear()
+                memo.update(fresh)
             return util._LazyValues(values, errors)
         return many
 
