@@ -293,3 +293,161 @@ def gp_logprob(comp, vals, mean, amp2, noise, ls):
     chol = spla.cholesky(c, lower=True)
     solve = spla.cho_solve((chol, True), vals - mean)
     return -np.sum(np.log(np.diag(chol))) - 0.5 * np.dot(vals - mean, solve)
+
+
+# --------------------------------------------------------------------------
+# EI + gradient at a point: the objective of the local refinement
+# (S/chooser/GPEIOptChooser.py:360-525; S/chooser/GPEIperSecChooser.py:322-434;
+#  covariance gradients S/gp.py:56-85, :129-132)
+# --------------------------------------------------------------------------
+def grad_dist2(ls, x1, x2=None):
+    """d r2(i,j) / d x1(i,d) for the ARD-scaled squared distance.  S/gp.py:56-85 (the numpy
+    fallback branch; scipy.weave no longer exists): gX[i,j,d] = 2 (x1[i,d] - x2[j,d]) (1/ls[d])
+    on the rescaled inputs."""
+    if x2 is None:
+        x2 = x1
+    x1 = x1 / ls
+    x2 = x2 / ls
+    gX = np.zeros((x1.shape[0], x2.shape[0], x1.shape[1]))
+    for i in range(x1.shape[0]):
+        gX[i, :, :] = 2 * (x1[i, :] - x2[:, :]) * (1 / ls)
+    return gX
+
+
+def grad_matern52(ls, x1, x2=None):
+    """S/gp.py:129-132: dk/dr2 * dr2/dx1; note r here is sqrt(dist2) without the abs."""
+    r = np.sqrt(dist2(ls, x1, x2))
+    grad_r2 = -(5.0 / 6.0) * np.exp(-SQRT_5 * r) * (1 + SQRT_5 * r)
+    return grad_r2[:, :, np.newaxis] * grad_dist2(ls, x1, x2)
+
+
+def grad_optimize_ei(cand, comp, vals, hyper):
+    """(-sum EI, gradient) at the point(s) ``cand`` under ONE hyper draw, no pending jobs.
+    GPEIOptChooser.py:391-440, including its factor one half in grad_xp."""
+    mean, noise, amp2, ls = unpack_hyper(hyper)
+    best = np.min(vals)
+    cand = np.reshape(cand, (-1, comp.shape[1]))
+    comp_cov = cov(amp2, ls, comp)
+    cand_cross = cov(amp2, ls, comp, cand)
+    obsv_cov = comp_cov + noise * np.eye(comp.shape[0])
+    obsv_chol = spla.cholesky(obsv_cov, lower=True)
+    cand_cross_grad = grad_matern52(ls, comp, cand)
+    alpha = spla.cho_solve((obsv_chol, True), vals - mean)
+    beta = spla.solve_triangular(obsv_chol, cand_cross, lower=True)
+    func_m = np.dot(cand_cross.T, alpha) + mean
+    func_v = amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
+    func_s = np.sqrt(func_v)
+    u = (best - func_m) / func_s
+    ncdf = sps.norm.cdf(u)
+    npdf = sps.norm.pdf(u)
+    ei = func_s * (u * ncdf + npdf)
+    g_ei_m = -ncdf
+    g_ei_s2 = 0.5 * npdf / func_s
+    grad_cross = np.squeeze(cand_cross_grad)
+    grad_xp_m = np.dot(alpha.transpose(), grad_cross)
+    grad_xp_v = np.dot(-2 * spla.cho_solve((obsv_chol, True), cand_cross).transpose(), grad_cross)
+    grad_xp = 0.5 * amp2 * (grad_xp_m * g_ei_m + grad_xp_v * g_ei_s2)
+    return -np.sum(ei), grad_xp.flatten()
+
+
+def grad_optimize_ei_pending(cand, comp, pend, vals, hyper, randn_ps):
+    """The pending branch of the same function (GPEIOptChooser.py:441-525): EI averaged over
+    the S fantasies and the mean of the per-fantasy gradients.  ``randn_ps`` is the (P, S)
+    normal matrix the reference obtains by restoring its saved RNG state (:476-477)."""
+    mean, noise, amp2, ls = unpack_hyper(hyper)
+    d = comp.shape[1]
+    cand = np.reshape(cand, (-1, d))
+    n = comp.shape[0]
+    comp_pend = np.concatenate((comp, pend))
+    cp_cov = cov(amp2, ls, comp_pend) + noise * np.eye(comp_pend.shape[0])
+    cp_chol = spla.cholesky(cp_cov, lower=True)
+    pend_cross = cov(amp2, ls, comp, pend)
+    pend_kappa = cov(amp2, ls, pend)
+    obsv_chol = cp_chol[:n, :n]
+    alpha = spla.cho_solve((obsv_chol, True), vals - mean)
+    beta = spla.cho_solve((obsv_chol, True), pend_cross)
+    pend_m = np.dot(pend_cross.T, alpha) + mean
+    pend_K = pend_kappa - np.dot(pend_cross.T, beta)
+    pend_chol = spla.cholesky(pend_K, lower=True)
+    pend_fant = np.dot(pend_chol, randn_ps) + pend_m[:, None]
+    S = randn_ps.shape[1]
+    fant_vals = np.concatenate((np.tile(vals[:, np.newaxis], (1, S)), pend_fant))
+    bests = np.min(fant_vals, axis=0)
+    cand_cross = cov(amp2, ls, comp_pend, cand)
+    cand_cross_grad = grad_matern52(ls, comp_pend, cand)
+    alpha = spla.cho_solve((cp_chol, True), fant_vals - mean)
+    beta = spla.solve_triangular(cp_chol, cand_cross, lower=True)
+    func_m = np.dot(cand_cross.T, alpha) + mean
+    func_v = amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
+    func_s = np.sqrt(func_v[:, np.newaxis])
+    u = (bests[np.newaxis, :] - func_m) / func_s
+    ncdf = sps.norm.cdf(u)
+    npdf = sps.norm.pdf(u)
+    ei = func_s * (u * ncdf + npdf)
+    g_ei_m = -ncdf
+    g_ei_s2 = 0.5 * npdf / func_s
+    if pend.shape[1] == 1:
+        grad_cross = np.squeeze(cand_cross_grad, axis=(2,))
+    else:
+        grad_cross = np.squeeze(cand_cross_grad)
+    grad_xp_m = np.dot(alpha.transpose(), grad_cross)
+    grad_xp_v = np.dot(-2 * spla.cho_solve((cp_chol, True), cand_cross).transpose(), grad_cross)
+    grad_xp = 0.5 * amp2 * (grad_xp_m * np.tile(g_ei_m, (d, 1)).T + (grad_xp_v.T * g_ei_s2).T)
+    return float(-np.mean(ei, axis=1)[0]), np.mean(grad_xp, axis=0).flatten()
+
+
+def grad_optimize_ei_per_s(cand, comp, vals, log_durs, hyper, time_hyper):
+    """EI per second and its gradient at a point.  GPEIperSecChooser.py:349-434."""
+    mean, noise, amp2, ls = unpack_hyper(hyper)
+    t_mean, t_noise, t_amp2, t_ls = unpack_hyper(time_hyper)
+    best = np.min(vals)
+    cand = np.reshape(cand, (-1, comp.shape[1]))
+    comp_time_cov = cov(t_amp2, t_ls, comp)
+    cand_time_cross = cov(t_amp2, t_ls, comp, cand)
+    obsv_time_chol = spla.cholesky(comp_time_cov + t_noise * np.eye(comp.shape[0]), lower=True)
+    t_alpha = spla.cho_solve((obsv_time_chol, True), log_durs - t_mean)
+    func_time_m = np.exp(np.dot(cand_time_cross.T, t_alpha) + t_mean)
+    grad_cross_t = np.squeeze(grad_matern52(t_ls, comp, cand))
+    comp_cov = cov(amp2, ls, comp)
+    cand_cross = cov(amp2, ls, comp, cand)
+    obsv_chol = spla.cholesky(comp_cov + noise * np.eye(comp.shape[0]), lower=True)
+    cand_cross_grad = grad_matern52(ls, comp, cand)
+    alpha = spla.cho_solve((obsv_chol, True), vals - mean)
+    beta = spla.solve_triangular(obsv_chol, cand_cross, lower=True)
+    func_m = np.dot(cand_cross.T, alpha) + mean
+    func_v = amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
+    func_s = np.sqrt(func_v)
+    u = (best - func_m) / func_s
+    ncdf = sps.norm.cdf(u)
+    npdf = sps.norm.pdf(u)
+    ei = func_s * (u * ncdf + npdf)
+    ei_per_s = -np.sum(ei / func_time_m)
+    grad_time_xp_m = np.dot(t_alpha.transpose(), grad_cross_t)
+    g_ei_m = -ncdf
+    g_ei_s2 = 0.5 * npdf / func_s
+    grad_cross = np.squeeze(cand_cross_grad)
+    grad_xp_m = np.dot(alpha.transpose(), grad_cross)
+    grad_xp_v = np.dot(-2 * spla.cho_solve((obsv_chol, True), cand_cross).transpose(), grad_cross)
+    grad_xp = 0.5 * amp2 * (grad_xp_m * g_ei_m + grad_xp_v * g_ei_s2)
+    grad_time_xp_m = 0.5 * t_amp2 * grad_time_xp_m * func_time_m
+    grad_xp = (func_time_m * grad_xp - ei * grad_time_xp_m) / (func_time_m ** 2)
+    return ei_per_s, grad_xp.flatten()
+
+
+def grad_optimize_ei_over_hypers(cand, comp, vals, hypers, pend=None, randn_ps=None,
+                                 log_durs=None, time_hypers=None):
+    """Summed over the hyper draws in draw order: the L-BFGS-B objective.
+    GPEIOptChooser.py:360-388; GPEIperSecChooser.py:322-347."""
+    summed_ei = 0
+    summed_grad = np.zeros(np.asarray(cand).shape).flatten()
+    hypers = np.atleast_2d(hypers)
+    for h in range(hypers.shape[0]):
+        if time_hypers is not None:
+            ei, g = grad_optimize_ei_per_s(cand, comp, vals, log_durs, hypers[h], np.atleast_2d(time_hypers)[h])
+        elif pend is not None and pend.shape[0] > 0:
+            ei, g = grad_optimize_ei_pending(cand, comp, pend, vals, hypers[h], randn_ps)
+        else:
+            ei, g = grad_optimize_ei(cand, comp, vals, hypers[h])
+        summed_grad = summed_grad + g
+        summed_ei += ei
+    return summed_ei, summed_grad

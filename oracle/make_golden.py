@@ -24,6 +24,9 @@ Fixtures (all float64, ref = the reference's own functions):
                    (seeded; burnin + MCMC + refinement), the point they propose.
   chooser_next_pending.npz  the same with three pending jobs (fantasy branch).
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
+  ei_grad.npz      the refinement objective: GPEIOptChooser.grad_optimize_ei_over_hypers
+                   without and with pending jobs, GPEIperSecChooser.grad_optimize_ei_over_hypers
+                   (value + gradient at several points each).
 """
 import os
 import sys
@@ -312,10 +315,66 @@ def gen_slice(mods, tmp):
                         lp_at_ones=lp_ls(np.ones(3)))
 
 
+def gen_ei_grad(mods, tmp):
+    """The L-BFGS-B objective of the local refinement, evaluated by the reference itself
+    (GPEIOptChooser.py:360-525, GPEIperSecChooser.py:322-434)."""
+    out = {}
+    # (1) no pending jobs, two problem sizes
+    for tag, (N, D, H, seed) in (("a", (40, 3, 3, 51)), ("b", (150, 9, 4, 52))):
+        comp, cand, vals, hypers = synthetic_problem(N, 12, D, H, seed)
+        opt = _mk_chooser(mods["GPEIOptChooser"], "GPEIOptChooser", tmp, mcmc_iters=H)
+        opt.D = D
+        _set(opt, hypers[0])
+        opt.hyper_samples = [(h[0], h[1], h[2], h[3:].copy()) for h in hypers]
+        rs = np.random.RandomState(seed)
+        pts = np.vstack((cand[:4], comp[np.argmin(vals)] + 1e-3 * rs.randn(D), comp[3] + 1e-3 * rs.randn(D), rs.rand(D)))
+        pend = np.zeros((0, D))
+        f = np.zeros(len(pts)); g = np.zeros((len(pts), D))
+        for i, x in enumerate(pts):
+            f[i], g[i] = opt.grad_optimize_ei_over_hypers(x.copy(), comp, pend, vals)
+        out.update({"%s_comp" % tag: comp, "%s_vals" % tag: vals, "%s_hypers" % tag: hypers,
+                    "%s_points" % tag: pts, "%s_f" % tag: f, "%s_g" % tag: g})
+    # (2) with pending jobs: fantasies from the replayed RNG state (:476-477)
+    N, D, H, P, S, seed = 60, 4, 3, 3, 11, 53
+    comp, cand, vals, hypers = synthetic_problem(N, 12, D, H, seed)
+    rs = np.random.RandomState(seed)
+    pend = rs.rand(P, D)
+    opt = _mk_chooser(mods["GPEIOptChooser"], "GPEIOptChooser", tmp, mcmc_iters=H, pending_samples=S)
+    opt.D = D
+    _set(opt, hypers[0])
+    opt.hyper_samples = [(h[0], h[1], h[2], h[3:].copy()) for h in hypers]
+    npr.seed(4242)
+    opt.randomstate = npr.get_state()
+    randn = npr.randn(P, S)                      # what every grad_optimize_ei call will draw
+    pts = np.vstack((cand[:3], comp[np.argmin(vals)] + 1e-3 * rs.randn(D), pend[0] + 1e-2 * rs.randn(D), rs.rand(D)))
+    f = np.zeros(len(pts)); g = np.zeros((len(pts), D))
+    for i, x in enumerate(pts):
+        fi, gi = opt.grad_optimize_ei_over_hypers(x.copy(), comp, pend, vals)
+        f[i], g[i] = float(np.ravel(fi)[0]), gi
+    out.update(p_comp=comp, p_pend=pend, p_vals=vals, p_hypers=hypers, p_randn=randn, p_points=pts, p_f=f, p_g=g)
+    # (3) EI per second
+    N, D, H, seed = 70, 5, 3, 54
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(N, 12, D, H, seed, per_sec=True)
+    ps = _mk_chooser(mods["GPEIperSecChooser"], "GPEIperSecChooser", tmp, mcmc_iters=H)
+    ps.D = D
+    _set(ps, hypers[0])
+    ps.time_mean, ps.time_noise, ps.time_amp2, ps.time_ls = th[0, 0], th[0, 1], th[0, 2], th[0, 3:].copy()
+    ps.hyper_samples = [(h[0], h[1], h[2], h[3:].copy()) for h in hypers]
+    ps.time_hyper_samples = [(h[0], h[1], h[2], h[3:].copy()) for h in th]
+    rs = np.random.RandomState(seed)
+    pts = np.vstack((cand[:3], comp[np.argmin(vals)] + 1e-3 * rs.randn(D), rs.rand(D)))
+    f = np.zeros(len(pts)); g = np.zeros((len(pts), D))
+    for i, x in enumerate(pts):
+        f[i], g[i] = ps.grad_optimize_ei_over_hypers(x.copy(), comp, vals, log_durs)
+    out.update(s_comp=comp, s_vals=vals, s_log_durs=log_durs, s_hypers=hypers, s_time_hypers=th,
+               s_points=pts, s_f=f, s_g=g)
+    np.savez_compressed(os.path.join(OUT, "ei_grad.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 

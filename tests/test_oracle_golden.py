@@ -132,3 +132,35 @@ def test_known_answers():
     # numpy argmax/mean tie + NaN rules the device code must reproduce
     assert np.argmax(np.array([1.0, np.nan, 5.0, np.nan])) == 1
     assert np.argmax(np.array([2.0, 5.0, 5.0])) == 1
+
+
+def test_refinement_objective_matches_reference(golden_dir):
+    """grad_optimize_ei_over_hypers of the reference (GPEIOptChooser.py:360-525,
+    GPEIperSecChooser.py:322-434): value and gradient, without / with pending jobs and per second."""
+    g = np.load(os.path.join(golden_dir, "ei_grad.npz"))
+    for tag in "ab":
+        for x, f_ref, g_ref in zip(g[tag + "_points"], g[tag + "_f"], g[tag + "_g"]):
+            f, gr = orc.grad_optimize_ei_over_hypers(x, g[tag + "_comp"], g[tag + "_vals"], g[tag + "_hypers"])
+            assert np.isclose(f, f_ref, rtol=1e-12, atol=0) and np.allclose(gr, g_ref, rtol=1e-10, atol=1e-300)
+    for x, f_ref, g_ref in zip(g["p_points"], g["p_f"], g["p_g"]):
+        f, gr = orc.grad_optimize_ei_over_hypers(x, g["p_comp"], g["p_vals"], g["p_hypers"],
+                                                 pend=g["p_pend"], randn_ps=g["p_randn"])
+        assert np.isclose(f, f_ref, rtol=1e-12, atol=0) and np.allclose(gr, g_ref, rtol=1e-10, atol=1e-300)
+    for x, f_ref, g_ref in zip(g["s_points"], g["s_f"], g["s_g"]):
+        f, gr = orc.grad_optimize_ei_over_hypers(x, g["s_comp"], g["s_vals"], g["s_hypers"],
+                                                 log_durs=g["s_log_durs"], time_hypers=g["s_time_hypers"])
+        assert np.isclose(f, f_ref, rtol=1e-12, atol=0) and np.allclose(gr, g_ref, rtol=1e-10, atol=1e-300)
+
+
+def test_refinement_objective_is_a_gradient():
+    """Central differences of the restated objective: the reference's gradient carries a factor
+    one half (GPEIOptChooser.py:437), so d f / d x = 2 * grad."""
+    from spearmint_amd.synthetic import synthetic_problem
+    comp, cand, vals, hypers = synthetic_problem(50, 5, 3, 2, 91, near=0)
+    x = cand[1].copy()
+    f0, gr = orc.grad_optimize_ei_over_hypers(x, comp, vals, hypers)
+    for d in range(3):
+        e = np.zeros(3); e[d] = 1e-6
+        num = (orc.grad_optimize_ei_over_hypers(x + e, comp, vals, hypers)[0]
+               - orc.grad_optimize_ei_over_hypers(x - e, comp, vals, hypers)[0]) / 2e-6
+        assert np.isclose(0.5 * num, gr[d], rtol=1e-4, atol=1e-10)
