@@ -58,6 +58,23 @@ typedef struct spx_handle spx_handle;
 /* Create an engine on HIP device `device_id` (lazy: the first call that needs
  * the GPU initialises it, so the handle can be created before a fork).       */
 int  spx_create(int device_id, spx_handle** out);
+/* One handle over n_dev GPUs of this node, for the single-process driver:
+ * every call below works on it unchanged.  Candidate rows are sharded contiguously over the
+ * devices, observations / hyper draws are replicated, each device is driven by its own host
+ * thread, and spx_ei_run ends with the path's single collective -- one ncclAllGather (RCCL over
+ * xGMI, communicator from ncclCommInitAll) of a 16-byte {best mean EI, global index} record per
+ * device, followed by the same numpy-argmax reduction on every device.  Results are bit-identical
+ * to a one-GPU handle (np.argmax(np.mean(overall_ei, axis=1)), GPEIChooser.py:153).
+ * spx_gp_logprob shards its draws and spx_ei_grad_batch its points over the devices.
+ * Repeated device ids (several engines on one GPU: test configuration) cannot form an RCCL
+ * communicator; the records then go through host memory (SPX_TRANSPORT_HOST).  librccl is
+ * loaded when this is first called, not when libspx is.                                        */
+int  spx_create_multi(const int* device_ids, int32_t n_dev, spx_handle** out);
+#define SPX_TRANSPORT_NONE 0   /* single-GPU handle: no collective                */
+#define SPX_TRANSPORT_RCCL 1   /* ncclAllGather over the devices' streams          */
+#define SPX_TRANSPORT_HOST 2   /* records staged through host memory               */
+/* n_dev, transport and (up to cap) device ids of a handle; any pointer may be NULL */
+int  spx_multi_query(spx_handle* h, int32_t* n_dev, int32_t* transport, int32_t* device_ids, int32_t cap);
 void spx_destroy(spx_handle* h);
 const char* spx_last_error(void);
 int  spx_version(void);
@@ -89,7 +106,7 @@ int spx_factor(spx_handle* h);
  * Call after spx_set_observations was given comp_pend = [comp; pend] (n = N + P rows; the
  * vals argument is then only a placeholder) and spx_factor has run:
  *   fant  H x n x S, per draw row-major [i][s]: fant_vals of :245-246 (tile(vals) on top of
- *         pend_fant);   bests H x S: np.min(fant_vals, axis=0) (:249).   1 <= S <= 128.
+ *         pend_fant);   bests H x S: np.min(fant_vals, axis=0) (:249).   1 <= S <= 4096.
  * The next spx_ei_run scores every candidate against every fantasy (:253-263) and averages
  * over S in numpy's summation order (:265).  NULL / S = 0 clears; so does any call that
  * invalidates the factorisation.                                                      */
@@ -141,12 +158,18 @@ int spx_get_time_mean(spx_handle* h, int32_t draw, double* out /* M */);
  * each resident draw (GPEIChooser.py:281-285): out has H entries, -inf where
  * the covariance is not PD.  Needs spx_set_observations + spx_set_hypers.      */
 int spx_gp_logprob(spx_handle* h, double* out);
-/* Objective of the local refinement (GPEIOptChooser.py:360-440; "next" row 3): at ONE point
- * (D doubles) the summed negative EI over the resident draws and its gradient, in the
- * reference's scaling (its grad_xp carries a factor one half).  Needs spx_factor or a
- * previous spx_ei_grid; observations without pending experiments.  When a time model was
- * factored (spx_set_time_model / spx_ei_per_sec_grid) the objective is EI per second and
- * its gradient (GPEIperSecChooser.py:349-434).                                           */
+/* Objective of the local refinement (GPEIOptChooser.py:360-525 grad_optimize_ei_over_hypers;
+ * "next" row 3) at P points in ONE call -- the reference runs grid_subset (20) L-BFGS-B problems,
+ * one objective evaluation at a time (:265-291): points (P x D) -> neg_ei[p] = the summed
+ * negative EI over the resident draws, grad (P x D) its gradient, in the reference's scaling (its
+ * grad_xp carries a factor one half).  A point's result does not depend on the other points of
+ * the call.  Needs spx_factor or a previous spx_ei_grid.  With fantasies set (spx_set_fantasies;
+ * the pending branch :441-525) EI and gradient are averaged over the S fantasies per draw; with
+ * a factored time model (spx_set_time_model / spx_ei_per_sec_grid) the objective is EI per second
+ * (GPEIperSecChooser.py:349-434; not combinable with fantasies, as in the reference).          */
+int spx_ei_grad_batch(spx_handle* h, const double* points, int32_t P, double* neg_ei /* P */,
+                      double* grad /* P x D */);
+/* == spx_ei_grad_batch with P = 1 */
 int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad /* D */);
 /* Sobol candidate grid on the device (ExperimentGrid.py:192-196 -> sobol_lib.py:125-157
  * i4_sobol_generate; "next" row 4): grid (n x dim, row-major) = transpose(i4_sobol_generate(dim,
@@ -166,7 +189,9 @@ int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot);
  * in the order of spx_timing_name(i); returns the number of stages.            */
 int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n);
 const char* spx_timing_name(int i);
-/* tuning knobs (bytes of the K(X*,X) staging buffer; 0 = default).            */
+/* tuning knobs: "kstar_budget_bytes" (K(X*,X) staging buffer; 0 = default), "streams" (1|2),
+ * "timing" (0|1), "gemm_waves" (predict-GEMM variant of THIS handle; values the build does not
+ * contain are rejected with SPX_ERR_ARG).                                                      */
 int spx_set_option(spx_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

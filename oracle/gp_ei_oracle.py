@@ -373,6 +373,17 @@ def grad_optimize_ei_pending(cand, comp, pend, vals, hyper, randn_ps):
     S = randn_ps.shape[1]
     fant_vals = np.concatenate((np.tile(vals[:, np.newaxis], (1, S)), pend_fant))
     bests = np.min(fant_vals, axis=0)
+    return grad_optimize_ei_fantasies(cand, comp_pend, hyper, fant_vals, bests)
+
+
+def grad_optimize_ei_fantasies(cand, comp_pend, hyper, fant_vals, bests):
+    """Second half of the pending branch (GPEIOptChooser.py:494-525) for given fantasy values
+    ((N+P) x S) and their minima: EI averaged over the fantasies, mean of the gradients."""
+    mean, noise, amp2, ls = unpack_hyper(hyper)
+    d = comp_pend.shape[1]
+    cand = np.reshape(cand, (-1, d))
+    cp_cov = cov(amp2, ls, comp_pend) + noise * np.eye(comp_pend.shape[0])
+    cp_chol = spla.cholesky(cp_cov, lower=True)
     cand_cross = cov(amp2, ls, comp_pend, cand)
     cand_cross_grad = grad_matern52(ls, comp_pend, cand)
     alpha = spla.cho_solve((cp_chol, True), fant_vals - mean)
@@ -386,7 +397,7 @@ def grad_optimize_ei_pending(cand, comp, pend, vals, hyper, randn_ps):
     ei = func_s * (u * ncdf + npdf)
     g_ei_m = -ncdf
     g_ei_s2 = 0.5 * npdf / func_s
-    if pend.shape[1] == 1:
+    if d == 1:
         grad_cross = np.squeeze(cand_cross_grad, axis=(2,))
     else:
         grad_cross = np.squeeze(cand_cross_grad)

@@ -3,8 +3,9 @@ few candidates refined by L-BFGS-B on the summed EI -- the MI355X drop-in for
 spearmint/spearmint/chooser/GPEIOptChooser.py.
 
 Both full passes over the candidate grid (GPEIOptChooser.py:269 and :293) run
-on the GPU; the refinement of `grid_subset` (=20) points stays on the host
-(it is a 20-point problem)."""
+on the GPU, and so does the objective of the `grid_subset` (=20) L-BFGS-B
+refinements: all points that wait for an
+evaluation share one spx_ei_grad_batch call (spearmint_amd/refine.py)."""
 from __future__ import absolute_import, print_function
 
 import os
@@ -14,6 +15,7 @@ import numpy.random as npr
 import scipy.optimize as spo
 
 from .. import hostgp
+from .. import refine
 from .. import util
 from ..helpers import log, unpickle
 from ._base import GPEIBase, _as_bool
@@ -115,33 +117,30 @@ class GPEIOptChooser(GPEIBase):
         return out
 
     def _refine(self, points, comp, vals, pend):
-        """L-BFGS-B on the summed EI of each kept point (:285-289).  Objective and
-        gradient come from the GPU (spx_ei_grad, against the factorisation the first
-        EI pass left resident) or, for tiny problems / pending jobs, from host models."""
-        if pend.shape[0] == 0 and self._use_gpu_refine(comp.shape[0]):
-            eng = self.engine()
-
-            def objective(x):
-                return eng.ei_grad(x)
-        else:
-            if pend.shape[0] > 0:
-                models = []
-                for h in self.hyper_samples:
-                    npr.set_state(self.randomstate)
-                    models.append(hostgp.PendingPointModel(comp, pend, vals, h,
-                                                           npr.randn(pend.shape[0], self.pending_samples)))
-            else:
-                models = [hostgp.PointModel(comp, vals, h) for h in self.hyper_samples]
-
-            def objective(x):
-                total, grad = 0.0, np.zeros(x.shape[0])
-                for m in models:
-                    e, g = m.neg_ei_and_grad(x)
-                    total += e
-                    grad = grad + g
-                return total, grad
-
+        """L-BFGS-B on the summed EI of each kept point (:285-289).  On the GPU all kept points are
+        optimised together: every instance's next objective evaluation goes into one
+        spx_ei_grad_batch call against the factorisation (and, with pending jobs, the fantasies)
+        the first EI pass left resident.  Tiny problems use host models, one point at a time."""
         bounds = [(0, 1)] * comp.shape[1]
+        if self._use_gpu_refine(comp.shape[0]):
+            return refine.lbfgs_many(self.engine().ei_grad_batch, points, bounds, log=log)
+        if pend.shape[0] > 0:
+            models = []
+            for h in self.hyper_samples:
+                npr.set_state(self.randomstate)
+                models.append(hostgp.PendingPointModel(comp, pend, vals, h,
+                                                       npr.randn(pend.shape[0], self.pending_samples)))
+        else:
+            models = [hostgp.PointModel(comp, vals, h) for h in self.hyper_samples]
+
+        def objective(x):
+            total, grad = 0.0, np.zeros(x.shape[0])
+            for m in models:
+                e, g = m.neg_ei_and_grad(x)
+                total += e
+                grad = grad + g
+            return total, grad
+
         out = np.array(points, dtype=float, copy=True)
         for i in range(out.shape[0]):
             log("Optimizing candidate %d/%d" % (i + 1, out.shape[0]))

@@ -19,6 +19,7 @@ import numpy.random as npr
 import scipy.optimize as spo
 
 from .. import hostgp
+from .. import refine
 from .. import util
 from ..helpers import log
 from ._base import GPEIBase, _as_bool
@@ -141,11 +142,9 @@ class GPEIperSecChooser(GPEIBase):
         here).  On the GPU the objective uses the dual factorisation the first pass left
         resident (spx_ei_grad); the bug-compatible mode pairs the draws as the reference does,
         which the resident pairing does not reproduce, so it stays on the host."""
+        bounds = [(0, 1)] * comp.shape[1]
         if self._use_gpu_refine(comp.shape[0]) and not self.ref_compat and self._resident_plain:
-            eng = self.engine()
-
-            def objective(x):
-                return eng.ei_grad(x)
+            return refine.lbfgs_many(self.engine().ei_grad_batch, points, bounds, log=log)
         else:
             rows, trows = (self.hyper_samples[:self.mcmc_iters],
                            (self.time_hyper_samples[:self.mcmc_iters] if self.ref_compat
@@ -160,7 +159,6 @@ class GPEIperSecChooser(GPEIBase):
                     grad = grad + g
                 return total, grad
 
-        bounds = [(0, 1)] * comp.shape[1]
         out = np.array(points, dtype=float, copy=True)
         for i in range(out.shape[0]):
             log("Optimizing candidate %d/%d" % (i + 1, out.shape[0]))

@@ -57,6 +57,9 @@ class GPEIBase(object):
         self.state_pkl = os.path.join(expt_dir, self.__module__ + ".pkl")
         self.mcmc_iters = int(mcmc_iters)
         self.pending_samples = int(pending_samples)
+        if not 1 <= self.pending_samples <= 4096:
+            raise ValueError("pending_samples must be in 1..4096 (got %d): the GPU path scores every "
+                             "candidate against that many fantasies per draw" % self.pending_samples)
         self.noiseless = _as_bool(noiseless)
         self.device = int(device)
         self.ndev = int(ndev)     # GPUs device .. device+ndev-1, candidates sharded over them
@@ -75,6 +78,7 @@ class GPEIBase(object):
             from .. import sobol as _sobol
             _sobol.install(device=self.device, log=log)
         self._lp_key = None
+        self._lp_refs = None
         self.D = -1
         self._eng = None          # created lazily in next(): never before a fork, never pickled
         self.last_overall_ei = None
@@ -83,7 +87,7 @@ class GPEIBase(object):
     def engine(self):
         if self._eng is None:
             from ..engine import Engine, MultiEngine
-            if self.ndev > 1:
+            if self.ndev > 1:   # one handle over ndev GPUs: sharding + the RCCL all-gather live in libspx
                 self._eng = MultiEngine(range(self.device, self.device + self.ndev), self.lib_path)
             else:
                 self._eng = Engine(self.device, self.lib_path)
@@ -152,21 +156,25 @@ class GPEIBase(object):
         if not self._use_gpu_logprob(comp.shape[0]):
             return hostgp.data_logprob(comp, vals, mean, amp2, noise, ls)
         eng = self.engine()
-        key = (id(comp), id(vals), comp.shape, float(vals[0]), float(vals[-1]))
+        self._resident_observations(eng, comp, vals)
+        eng.set_hypers(np.concatenate(([mean, noise, amp2], np.asarray(ls, dtype=float)))[None, :])
+        return float(eng.gp_logprob(raise_not_pd=True)[0])
+
+    def _resident_observations(self, eng, comp, vals):
+        """Upload (comp, vals) unless the engine already holds these very arrays.  The cache keeps
+        references to the arrays it was filled from, so CPython cannot hand their ids to new arrays
+        while the entry is alive; sample_hypers() and every EI pass drop the entry."""
+        key = (id(comp), id(vals), comp.shape)
         if self._lp_key != key:
             eng.set_observations(comp, vals)
             self._lp_key = key
-        eng.set_hypers(np.concatenate(([mean, noise, amp2], np.asarray(ls, dtype=float)))[None, :])
-        return float(eng.gp_logprob(raise_not_pd=True)[0])
+            self._lp_refs = (comp, vals)
 
     def data_logprob_many(self, comp, vals, rows):
         """The data term for several hyper rows [mean, noise, amp2, ls...] in ONE GPU call
         (the batched factorisation has the latency of a single one).  Returns (values, not_pd)."""
         eng = self.engine()
-        key = (id(comp), id(vals), comp.shape, float(vals[0]), float(vals[-1]))
-        if self._lp_key != key:
-            eng.set_observations(comp, vals)
-            self._lp_key = key
+        self._resident_observations(eng, comp, vals)
         eng.set_hypers(rows)
         lp = eng.gp_logprob()
         return lp, np.isneginf(lp)
@@ -276,6 +284,7 @@ class GPEIBase(object):
         return util.slice_sample(ls, logprob, compwise=True)
 
     def sample_hypers(self, comp, vals):
+        self._lp_key = None       # whatever the engine holds from an earlier call is not trusted
         if self.noiseless:
             self.noise = 1e-3
         self.mean, self.amp2, self.noise = self._draw_mean_amp_noise(

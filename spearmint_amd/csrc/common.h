@@ -55,27 +55,31 @@ void launch_logprob(hipStream_t s, const double* L, const double* gamma, size_t 
                     double* out, int Np, int nh);
 
 // refine_kernels.hip
+#define SPX_REFINE_PB 8   // points (right-hand sides) that share one pass over W in the refinement kernels
 void launch_point_cov(hipStream_t s, const double* Xs, const double* s1, const double* hyp,
                       const double* htab, const double* x, double* kvec, double* dkdr2, int N, int Np,
-                      int D, int Dp, int nh);
+                      int D, int Dp, int nh, int P);
+void launch_trimv_multi(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh, int P);
+void launch_trimvT_multi(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh, int P);
 void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, const double* htab,
                          const double* alpha, const double* kvec, const double* dkdr2,
                          const double* tvec, const double* zvec, const double* x, double best,
-                         double* out, int N, int Np, int D, int Dp, int nh, const double* kt = nullptr,
-                         const double* dkt = nullptr);
+                         double* out, int N, int Np, int D, int Dp, int nh, int P, const double* kt,
+                         const double* dkt, int S, const double* gammaS, const double* alphaS,
+                         const double* bests, double* uvec);
 
 // sobol_kernels.hip
 void launch_sobol_grid(hipStream_t s, const uint32_t* dirs, int dim, int64_t n, int64_t skip, double* out);
 
 // predict_kernels.hip
-void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
-                         double* part_ss, double* part_bg, int Np, int Mc, int nh,
+void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const double* Kst, const double* gamma,
+                         double* part_ss, double* part_bg, int Np, int Mc, int nh, int part_nh, int part_h0,
                          const double* gammaS = nullptr, int S = 0, double* part_bgS = nullptr);
-void set_predict_gemm_waves(int nw);
+bool predict_gemm_variant_ok(int v);
 void launch_ei_finalize_fant(hipStream_t s, const double* part_ss, const double* part_bgS,
                              const double* htab, const double* bests, const double* time_m,
                              double* ei_draw, int nrb, int Mc, int nh, int S, int64_t c0, int64_t M,
-                             int64_t Mp, int h0);
+                             int64_t Mp, int h0, double* ei_s);
 void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part_bg,
                         const double* htab, const double* time_m, double best, double* ei_draw,
                         double* mom_m, double* mom_v, int nrb, int Mc, int nh, int64_t c0,

@@ -26,7 +26,7 @@
 //   tile 128(i) x 128(c), 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles,
 //   K loop over j in steps of 16, register-staged double-buffered LDS.
 // Grid: 1-D, XCD-aware (see the block -> tile map below), heaviest row blocks first.
-// part_ss / part_bg: [nrb][nh][Mc]
+// part_ss / part_bg: [nrb][part_nh][Mc] (all draws of a candidate chunk; this launch fills draws part_h0 ...)
 // ---------------------------------------------------------------------------
 // NW = waves per workgroup: 4 (wave tile 64x64) or 8 (wave tile 32x64).
 // STG = how the operand tiles reach LDS: 0 registers + ds_write (prefetch distance one tile),
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     const double* __restrict__ WT, const double* __restrict__ Kst,
     const double* __restrict__ gamma, double* __restrict__ part_ss,
     double* __restrict__ part_bg, int Np, int Mc, int nh, int ncb, int nrb,
+    int part_nh /*draws per chunk in part_ss / part_bg*/, int part_h0 /*first draw of this launch there*/,
     const double* __restrict__ gammaS /*[nh][S][Np] or null*/, int S,
     double* __restrict__ part_bgS /*[nrb][2][nh][S][Mc]*/)
 {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
             ss += red[(w * BN + tid) * 2 + 0];
             bg += red[(w * BN + tid) * 2 + 1];
         }
-        const size_t o = ((size_t)ib * nh + h) * Mc + (size_t)cb * BN + tid;
+        const size_t o = ((size_t)ib * part_nh + part_h0 + h) * Mc + (size_t)cb * BN + tid;
         part_ss[o] = ss;
         part_bg[o] = bg;
     }
@@ -290,27 +291,37 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     }
 }
 
-// variant selector (process-wide, spx_set_option "gemm_waves"): 0 = default (= 14),
-// 4 / 8 = waves per workgroup with register staging, 14 / 18 = same with LDS-DMA staging,
-// 24 = LDS-DMA with three 8-row buffers and two tiles in flight (counted vmcnt + raw s_barrier),
-// 41..43 = timing-only ablations of the 4-wave register-staged kernel.
-static int g_gemm_variant = 0;
-void set_predict_gemm_waves(int v) { g_gemm_variant = v; }
+// Variants (spx_set_option "gemm_waves", per handle): 0 / 14 = production (4 waves, LDS-DMA staging,
+// measured fastest), 4 / 8 = 4 / 8 waves with register staging, 18 = 8 waves with LDS-DMA, 24 = LDS-DMA
+// with three 8-row buffers and two tiles in flight.  All of these produce identical results.  The
+// timing-only ablations 41..44 (WRONG results, for performance analysis) exist only in a library
+// built with -DSPX_ABLATIONS (make ABLATIONS=1); the shipped library rejects them.
+bool predict_gemm_variant_ok(int v)
+{
+    switch (v) {
+        case 0: case 4: case 8: case 14: case 18: case 24: return true;
+#ifdef SPX_ABLATIONS
+        case 41: case 42: case 43: case 44: return true;
+#endif
+        default: return false;
+    }
+}
 
 template <int NW, int STG, int ABL>
 static void launch_gemm_variant(hipStream_t s, int grid, size_t lds, const double* WT, const double* Kst,
                                 const double* gamma, double* part_ss, double* part_bg, int Np, int Mc, int nh,
-                                int ncb, int nrb, const double* gammaS, int S, double* part_bgS)
+                                int ncb, int nrb, int part_nh, int part_h0, const double* gammaS, int S,
+                                double* part_bgS)
 {
     // attribute set per launch (not cached): it is per device, and one process may drive several GPUs
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm<NW, STG, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_predict_gemm<NW, STG, ABL>), dim3(grid), dim3(64 * NW), lds, s, WT, Kst, gamma, part_ss,
-                       part_bg, Np, Mc, nh, ncb, nrb, gammaS, S, part_bgS);
+                       part_bg, Np, Mc, nh, ncb, nrb, part_nh, part_h0, gammaS, S, part_bgS);
 }
 
-void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, const double* gamma,
-                         double* part_ss, double* part_bg, int Np, int Mc, int nh,
+void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const double* Kst, const double* gamma,
+                         double* part_ss, double* part_bg, int Np, int Mc, int nh, int part_nh, int part_h0,
                          const double* gammaS, int S, double* part_bgS)
 {
     const int ncb = Mc / BN, nrb = Np / BM;
@@ -318,19 +329,20 @@ void launch_predict_gemm(hipStream_t s, const double* WT, const double* Kst, con
     const int grid = 8 * ((ncb + 7) / 8) * nrb * nh;
 #define SPX_GO(NW_, STG_, ABL_)                                                                               \
     launch_gemm_variant<NW_, STG_, ABL_>(s, grid, lds, WT, Kst, gamma, part_ss, part_bg, Np, Mc, nh, ncb, nrb, \
-                                         gammaS, S, part_bgS)
-    const int v = (S > 0) ? 0 : g_gemm_variant;   // the fantasy epilogue exists in the 4-wave kernels
+                                         part_nh, part_h0, gammaS, S, part_bgS)
+    const int v = (S > 0) ? 0 : variant;   // the fantasy epilogue exists in the 4-wave kernels
     switch (v) {
         case 8:  SPX_GO(8, 0, 0); break;
-        case 14: SPX_GO(4, 1, 0); break;
         case 18: SPX_GO(8, 1, 0); break;
         case 24: SPX_GO(4, 2, 0); break;
+        case 4:  SPX_GO(4, 0, 0); break;
+#ifdef SPX_ABLATIONS
         case 41: SPX_GO(4, 0, 1); break;
         case 42: SPX_GO(4, 0, 2); break;
         case 43: SPX_GO(4, 0, 3); break;
         case 44: SPX_GO(4, 1, 4); break;
-        case 4:  SPX_GO(4, 0, 0); break;
-        default: SPX_GO(4, 1, 0); break;   // production: 4 waves, LDS-DMA staging (measured fastest)
+#endif
+        default: SPX_GO(4, 1, 0); break;   // production: 4 waves, LDS-DMA staging
     }
 #undef SPX_GO
 }
@@ -401,13 +413,15 @@ void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part
                        htab, time_m, best, ei_draw, mom_m, mom_v, nrb, Mc, nh, c0, M, Mp, h0);
 }
 
+__device__ double np_pairwise(const double* a, int64_t stride, int n);
+
 // EI against S fantasies, averaged over S in numpy's pairwise order
-// (np.mean(ei, axis=1) on the (M, S) array of GPEIChooser.py:261-266; S <= 128).
+// (np.mean(ei, axis=1) on the (M, S) array of GPEIChooser.py:261-266).
 __global__ __launch_bounds__(256) void k_ei_finalize_fant(
     const double* __restrict__ part_ss, const double* __restrict__ part_bgS,
     const double* __restrict__ htab, const double* __restrict__ bests /*[nh][S]*/,
     const double* __restrict__ time_m, double* __restrict__ ei_draw, int nrb, int Mc, int nh,
-    int S, int64_t c0, int64_t M, int64_t Mp, int h0)
+    int S, int64_t c0, int64_t M, int64_t Mp, int h0, double* __restrict__ ei_s /*[nh][S][Mc] when S > 128*/)
 {
 #pragma clang fp contract(off)
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -429,8 +443,10 @@ __global__ __launch_bounds__(256) void k_ei_finalize_fant(
             bg += part_bgS[o0] + part_bgS[o1];
         }
         const double ei = ei_dev(bg + mean, func_v, bh[sidx]);
-        // numpy pairwise_sum for n <= 128, streamed
-        if (S < 8) {
+        // numpy pairwise_sum: streamed for n <= 128, through memory (recursive halving) beyond
+        if (S > 128) {
+            ei_s[((size_t)h * S + sidx) * Mc + c] = ei;
+        } else if (S < 8) {
             res += ei;
         } else if (sidx < 8) {
             r8[sidx] = ei;
@@ -441,7 +457,8 @@ __global__ __launch_bounds__(256) void k_ei_finalize_fant(
             res += ei;
         }
     }
-    if (S >= 8 && nfull == S) res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+    if (S > 128) res = np_pairwise(ei_s + (size_t)h * S * Mc + c, Mc, S);
+    else if (S >= 8 && nfull == S) res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
     double out = (0.0 + res) / (double)S;
     if (time_m) out = out / time_m[(size_t)h * Mc + c];
     ei_draw[(size_t)(h0 + h) * Mp + c0 + c] = out;
@@ -450,10 +467,10 @@ __global__ __launch_bounds__(256) void k_ei_finalize_fant(
 void launch_ei_finalize_fant(hipStream_t s, const double* part_ss, const double* part_bgS,
                              const double* htab, const double* bests, const double* time_m,
                              double* ei_draw, int nrb, int Mc, int nh, int S, int64_t c0, int64_t M,
-                             int64_t Mp, int h0)
+                             int64_t Mp, int h0, double* ei_s)
 {
     hipLaunchKernelGGL(k_ei_finalize_fant, dim3((Mc + 255) / 256, nh), dim3(256), 0, s, part_ss,
-                       part_bgS, htab, bests, time_m, ei_draw, nrb, Mc, nh, S, c0, M, Mp, h0);
+                       part_bgS, htab, bests, time_m, ei_draw, nrb, Mc, nh, S, c0, M, Mp, h0, ei_s);
 }
 
 // ---------------------------------------------------------------------------

@@ -8,103 +8,32 @@
 #include <string>
 #include <vector>
 
-#include "../../include/spx.h"
-#include "common.h"
+#include "spx_internal.h"
 
-#define SPX_VERSION 101
+#define SPX_VERSION 200
 
-static thread_local std::string g_err;
+static const char* kStageNames[ST_COUNT] = {
+    "scale_rows", "cov_self", "chol_diag", "chol_panel", "trinv", "gamma_alpha",
+    "cov_cross", "cross_mean", "predict_gemm", "ei_finalize", "mean_argmax",
+    "factor_total", "ei_run_total"};
 
-static int fail(int code, const char* fmt, ...)
+
+std::string& spx_err_slot()
+{
+    static thread_local std::string g_err;
+    return g_err;
+}
+
+int spx_fail(int code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_err = buf;
+    spx_err_slot() = buf;
     return code;
 }
-
-#define HIPCHK(call)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(SPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
-                        __FILE__, __LINE__);                                                  \
-    } while (0)
-
-// grow-only device buffer
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes)
-    {
-        if (bytes <= cap) return SPX_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess)
-            return fail(SPX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        cap = bytes;
-        return SPX_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    double* d() const { return (double*)p; }
-};
-
-enum Stage {
-    ST_SCALE = 0, ST_COV_SELF, ST_CHOL_DIAG, ST_CHOL_PANEL, ST_TRINV, ST_GAMMA_ALPHA,
-    ST_COV_CROSS, ST_CROSS_MEAN, ST_PREDICT_GEMM, ST_EI_FINALIZE, ST_MEAN_ARGMAX,
-    ST_FACTOR_TOTAL, ST_EI_RUN_TOTAL, ST_COUNT
-};
-static const char* kStageNames[ST_COUNT] = {
-    "scale_rows", "cov_self", "chol_diag", "chol_panel", "trinv", "gamma_alpha",
-    "cov_cross", "cross_mean", "predict_gemm", "ei_finalize", "mean_argmax",
-    "factor_total", "ei_run_total"};
-
-struct spx_handle {
-    int device = 0;
-    bool inited = false;
-    hipStream_t stream = nullptr;    // main stream (also the only one the factorization uses)
-    hipStream_t stream2 = nullptr;   // optional producer stream (option "streams" = 2): K(X*,X) of the next
-                                     // work item is generated (VALU) while the GEMM of the current one runs (MFMA)
-    hipEvent_t ev_sync[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // whole-stage timers (factor / ei_run)
-
-    int64_t N = 0, M = 0, index_base = 0;
-    int D = 0, Dp = 0, Np = 0, H = 0;
-    bool have_obs = false, have_cand = false, have_hyp = false, have_time = false;
-    bool factored = false, ran = false, ran_moments = false;
-    int nmodels = 1;  // 1 = objective GP only, 2 = + log-duration GP
-    double best = 0.0;
-    int not_pd_draw = -1, not_pd_pivot = -1;
-    int64_t kst_budget = 512ll << 20;   // K(X*,X) staging buffer per stream (bytes)
-    int nstreams = 1;
-
-    std::vector<double> hyp_host, thyp_host;
-
-    DevBuf comp, vals, ldur, cand, hyp, htab;
-    DevBuf Xs, X2s, s1, Lm, WT, Dinv, gamma, alpha, info, lp;
-    DevBuf Cs[2], s2[2], Kst[2], part_ss[2], part_bg[2], time_m[2], ei_draw, ei_mean, mom_m, mom_v, mom_t;
-    DevBuf am_val, am_idx, am_out_val, am_out_idx, scratch;
-    // pending-experiment fantasies (spx_set_fantasies): S right-hand sides per draw
-    int S = 0;
-    DevBuf fantT, gammaS, bests, part_bgS[2];
-    DevBuf pt_x, pt_k, pt_dk, pt_t, pt_z, pt_out, pt_kt, pt_dkt;   // spx_ei_grad work vectors
-    DevBuf sobol_dirs, sobol_out;                                   // spx_sobol_grid
-    DevBuf rhs;                                                     // spx_gp_logprob: [H][64][Np] right-hand-side rows
-
-    double best_val = 0.0;
-    int64_t best_idx = -1;
-
-    // timing
-    bool timing = false;
-    struct Ev { hipEvent_t a, b; int stage; };
-    std::vector<Ev> ev_pool;
-    size_t ev_used = 0;
-    double st_ms[ST_COUNT] = {0};
-    int64_t st_n[ST_COUNT] = {0};
-};
 
 static int ensure_init(spx_handle* h)
 {
@@ -156,6 +85,8 @@ static void ev_collect(spx_handle* h)
     } while (0)
 #define TIMED(stage, stmt) TIMED_S(stage, h->stream, stmt)
 
+int spx_ensure_init(spx_handle* h) { return ensure_init(h); }
+
 static int padded_dim(int D)
 {
     if (D <= 4) return 4;
@@ -167,7 +98,7 @@ static int padded_dim(int D)
 extern "C" {
 
 int spx_version(void) { return SPX_VERSION; }
-const char* spx_last_error(void) { return g_err.c_str(); }
+const char* spx_last_error(void) { return spx_err_slot().c_str(); }
 
 int spx_device_count(void)
 {
@@ -189,6 +120,7 @@ int spx_create(int device_id, spx_handle** out)
 void spx_destroy(spx_handle* h)
 {
     if (!h) return;
+    if (h->multi) { spx_multi_destroy(h->multi); delete h; return; }
     if (h->inited) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
@@ -215,12 +147,15 @@ void spx_destroy(spx_handle* h)
 int spx_set_option(spx_handle* h, const char* name, int64_t value)
 {
     if (!h || !name) return fail(SPX_ERR_ARG, "spx_set_option: null");
+    if (h->multi) return spx_multi_set_option(h->multi, name, value);
     if (!strcmp(name, "kstar_budget_bytes")) {
         h->kst_budget = value > 0 ? value : (512ll << 20);
         return SPX_OK;
     }
-    if (!strcmp(name, "gemm_waves")) {   // 4 (default) or 8 waves per predict-GEMM workgroup (process-wide)
-        set_predict_gemm_waves((int)value);
+    if (!strcmp(name, "gemm_waves")) {   // predict-GEMM variant of this handle (predict_kernels.hip)
+        if (!predict_gemm_variant_ok((int)value))
+            return fail(SPX_ERR_ARG, "spx_set_option: gemm_waves=%lld is not a variant of this build", (long long)value);
+        h->gemm_variant = (int)value;
         return SPX_OK;
     }
     if (!strcmp(name, "streams")) {  // 1 = everything on one stream (default), 2 = alternate EI work items
@@ -238,6 +173,7 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
 
 int spx_set_observations(spx_handle* h, const double* comp, const double* vals, int64_t N, int32_t D)
 {
+    if (h && h->multi) return spx_multi_set_observations(h->multi, comp, vals, N, D);
     if (!h || !comp || !vals || N < 1 || D < 1 || N > (1 << 20))
         return fail(SPX_ERR_ARG, "spx_set_observations: bad arguments (N=%lld, D=%d)", (long long)N, D);
     int rc = ensure_init(h);
@@ -262,6 +198,7 @@ int spx_set_observations(spx_handle* h, const double* comp, const double* vals, 
 
 int spx_set_candidates(spx_handle* h, const double* cand, int64_t M, int32_t D, int64_t index_base)
 {
+    if (h && h->multi) return spx_multi_set_candidates(h->multi, cand, M, D, index_base);
     if (!h || !cand || M < 1 || D < 1)
         return fail(SPX_ERR_ARG, "spx_set_candidates: bad arguments (M=%lld, D=%d)", (long long)M, D);
     if (h->have_obs && D != h->D)
@@ -279,6 +216,7 @@ int spx_set_candidates(spx_handle* h, const double* cand, int64_t M, int32_t D, 
 
 int spx_set_hypers(spx_handle* h, const double* hypers, int32_t H)
 {
+    if (h && h->multi) return spx_multi_set_hypers(h->multi, hypers, H);
     if (!h || !hypers || H < 1) return fail(SPX_ERR_ARG, "spx_set_hypers: bad arguments (H=%d)", H);
     if (!h->have_obs) return fail(SPX_ERR_ARG, "spx_set_hypers: call spx_set_observations first");
     h->H = H;
@@ -290,6 +228,7 @@ int spx_set_hypers(spx_handle* h, const double* hypers, int32_t H)
 int spx_set_time_model(spx_handle* h, const double* log_durs, const double* time_hypers)
 {
     if (!h) return fail(SPX_ERR_ARG, "spx_set_time_model: null handle");
+    if (h->multi) return spx_multi_set_time_model(h->multi, log_durs, time_hypers);
     if (!log_durs || !time_hypers) { h->have_time = false; h->factored = false; return SPX_OK; }
     if (!h->have_obs || !h->have_hyp)
         return fail(SPX_ERR_ARG, "spx_set_time_model: set observations and hypers first");
@@ -411,12 +350,14 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
 int spx_factor(spx_handle* h)
 {
     if (!h) return fail(SPX_ERR_ARG, "spx_factor: null handle");
+    if (h->multi) return spx_multi_factor(h->multi);
     return do_factor(h, false);
 }
 
 int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot)
 {
     if (!h) return fail(SPX_ERR_ARG, "null handle");
+    if (h->multi) return spx_multi_not_pd_info(h->multi, draw, pivot);
     if (draw) *draw = h->not_pd_draw;
     if (pivot) *pivot = h->not_pd_pivot;
     return SPX_OK;
@@ -425,9 +366,10 @@ int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot)
 int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, int32_t S)
 {
     if (!h) return fail(SPX_ERR_ARG, "spx_set_fantasies: null handle");
+    if (h->multi) return spx_multi_set_fantasies(h->multi, fant, bests, S);
     if (!fant || !bests || S <= 0) { h->S = 0; return SPX_OK; }   // clear
     if (!h->factored) return fail(SPX_ERR_ARG, "spx_set_fantasies: call spx_factor first");
-    if (S > 128) return fail(SPX_ERR_ARG, "spx_set_fantasies: at most 128 fantasies (got %d)", S);
+    if (S > 4096) return fail(SPX_ERR_ARG, "spx_set_fantasies: at most 4096 fantasies (got %d)", S);
     int rc = ensure_init(h);
     if (rc) return rc;
     const int H = h->H, Np = h->Np;
@@ -450,6 +392,7 @@ int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, in
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     h->S = S;
+    h->alphaS_valid = false;
     h->ran = false;
     return SPX_OK;
 }
@@ -475,6 +418,7 @@ static void plan_chunks(const spx_handle* h, int64_t* Mc, int* Hb)
 int spx_ei_run(spx_handle* h, int32_t flags)
 {
     if (!h) return fail(SPX_ERR_ARG, "spx_ei_run: null handle");
+    if (h->multi) return spx_multi_ei_run(h->multi, flags);
     if (!h->factored) return fail(SPX_ERR_ARG, "spx_ei_run: call spx_factor first");
     if (!h->have_cand) return fail(SPX_ERR_ARG, "spx_ei_run: no candidates set");
     const bool per_sec = (flags & SPX_FLAG_PER_SEC) != 0;
@@ -509,11 +453,14 @@ int spx_ei_run(spx_handle* h, int32_t flags)
         if (per_sec && (rc = h->time_m[b].reserve((size_t)H * Mc * 8))) return rc;
         if (b < ns) {
             if ((rc = h->Kst[b].reserve((size_t)Hb * Np * Mc * 8))) return rc;
-            if ((rc = h->part_ss[b].reserve((size_t)nrb * Hb * Mc * 8))) return rc;
-            if ((rc = h->part_bg[b].reserve((size_t)nrb * Hb * Mc * 8))) return rc;
             if (S > 0 && (rc = h->part_bgS[b].reserve((size_t)nrb * 2 * S * Mc * 8))) return rc;
         }
     }
+    // column sums of beta^2 and beta*gamma per row block for ALL draws of a chunk: written by the
+    // GEMM launches and read by one EI-finalize launch per chunk, all on the consumer stream
+    if ((rc = h->part_ss[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
+    if ((rc = h->part_bg[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
+    if (S > 128 && (rc = h->scratch.reserve((size_t)S * Mc * 8))) return rc;
     if ((rc = h->ei_draw.reserve((size_t)H * Mp * 8))) return rc;
     if ((rc = h->ei_mean.reserve((size_t)Mp * 8))) return rc;
     if (keep_mom) {
@@ -576,25 +523,25 @@ int spx_ei_run(spx_handle* h, int32_t flags)
                 HIPCHK(hipEventRecord(h->ev_sync[k], P));
                 HIPCHK(hipStreamWaitEvent(G, h->ev_sync[k], 0));
             }
-            TIMED_S(ST_PREDICT_GEMM, G, launch_predict_gemm(G, h->WT.d() + (size_t)h0 * nn, h->Kst[k].d(),
-                                                            h->gamma.d() + (size_t)h0 * Np, h->part_ss[k].d(),
-                                                            h->part_bg[k].d(), Np, mc, nhb,
+            // with fantasies (Hb = 1) the launch's partial sums are consumed right away and sit at draw 0
+            TIMED_S(ST_PREDICT_GEMM, G, launch_predict_gemm(G, h->gemm_variant, h->WT.d() + (size_t)h0 * nn, h->Kst[k].d(),
+                                                            h->gamma.d() + (size_t)h0 * Np, h->part_ss[0].d(),
+                                                            h->part_bg[0].d(), Np, mc, nhb, S > 0 ? nhb : H, S > 0 ? 0 : h0,
                                                             S > 0 ? h->gammaS.d() + (size_t)h0 * S * Np : nullptr, S,
                                                             S > 0 ? h->part_bgS[k].d() : nullptr));
             if (S > 0)
-                TIMED_S(ST_EI_FINALIZE, G, launch_ei_finalize_fant(G, h->part_ss[k].d(), h->part_bgS[k].d(),
+                TIMED_S(ST_EI_FINALIZE, G, launch_ei_finalize_fant(G, h->part_ss[0].d(), h->part_bgS[k].d(),
                                                                    h->htab.d() + (size_t)h0 * SPX_HT,
                                                                    h->bests.d() + (size_t)h0 * S,
                                                                    per_sec ? tm + (size_t)h0 * mc : nullptr,
-                                                                   h->ei_draw.d(), nrb, mc, nhb, S, c0, M, Mp, h0));
-            else
-                TIMED_S(ST_EI_FINALIZE, G, launch_ei_finalize(G, h->part_ss[k].d(), h->part_bg[k].d(),
-                                                              h->htab.d() + (size_t)h0 * SPX_HT,
-                                                              per_sec ? tm + (size_t)h0 * mc : nullptr, h->best,
-                                                              h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
-                                                              keep_mom ? h->mom_v.d() : nullptr, nrb, mc, nhb, c0, M, Mp, h0));
+                                                                   h->ei_draw.d(), nrb, mc, nhb, S, c0, M, Mp, h0,
+                                                                   S > 128 ? h->scratch.d() : nullptr));
             if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[2 + k], G));
         }
+        if (S == 0)   // every draw of the chunk in one launch
+            TIMED_S(ST_EI_FINALIZE, G, launch_ei_finalize(G, h->part_ss[0].d(), h->part_bg[0].d(), h->htab.d(), tm, h->best,
+                                                          h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
+                                                          keep_mom ? h->mom_v.d() : nullptr, nrb, mc, H, c0, M, Mp, 0));
         if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[4 + par], G));
     }
     if (ns == 2 && per_sec && keep_mom) {   // the duration copies ran on P
@@ -624,6 +571,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
 
 int spx_get_best(spx_handle* h, int64_t* best_idx, double* best_val)
 {
+    if (h && h->multi) return spx_multi_get_best(h->multi, best_idx, best_val);
     if (!h || !h->ran) return fail(SPX_ERR_ARG, "spx_get_best: no results (call spx_ei_run)");
     if (best_idx) *best_idx = h->best_idx + h->index_base;
     if (best_val) *best_val = h->best_val;
@@ -632,6 +580,7 @@ int spx_get_best(spx_handle* h, int64_t* best_idx, double* best_val)
 
 int spx_get_ei_mean(spx_handle* h, double* out)
 {
+    if (h && h->multi) return spx_multi_get_ei_mean(h->multi, out);
     if (!h || !out || !h->ran) return fail(SPX_ERR_ARG, "spx_get_ei_mean: no results / null output");
     int rc = ensure_init(h);
     if (rc) return rc;
@@ -641,6 +590,7 @@ int spx_get_ei_mean(spx_handle* h, double* out)
 
 int spx_get_ei_draws(spx_handle* h, double* out)
 {
+    if (h && h->multi) return spx_multi_get_ei_draws(h->multi, out);
     if (!h || !out || !h->ran) return fail(SPX_ERR_ARG, "spx_get_ei_draws: no results / null output");
     int rc = ensure_init(h);
     if (rc) return rc;
@@ -655,6 +605,7 @@ int spx_get_ei_draws(spx_handle* h, double* out)
 
 int spx_get_moments(spx_handle* h, int32_t draw, double* func_m, double* func_v)
 {
+    if (h && h->multi) return spx_multi_get_moments(h->multi, draw, func_m, func_v);
     if (!h || !h->ran || !h->ran_moments)
         return fail(SPX_ERR_ARG, "spx_get_moments: run spx_ei_run with SPX_FLAG_KEEP_MOMENTS first");
     if (draw < 0 || draw >= h->H) return fail(SPX_ERR_ARG, "spx_get_moments: draw out of range");
@@ -668,6 +619,7 @@ int spx_get_moments(spx_handle* h, int32_t draw, double* func_m, double* func_v)
 
 int spx_get_time_mean(spx_handle* h, int32_t draw, double* out)
 {
+    if (h && h->multi) return spx_multi_get_time_mean(h->multi, draw, out);
     if (!h || !out || !h->ran || !h->ran_moments || h->nmodels != 2)
         return fail(SPX_ERR_ARG, "spx_get_time_mean: run spx_ei_run with SPX_FLAG_PER_SEC | SPX_FLAG_KEEP_MOMENTS first");
     if (draw < 0 || draw >= h->H) return fail(SPX_ERR_ARG, "spx_get_time_mean: draw out of range");
@@ -680,6 +632,7 @@ int spx_get_time_mean(spx_handle* h, int32_t draw, double* out)
 
 int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* alpha)
 {
+    if (h && h->multi) return spx_multi_get_factor(h->multi, draw, K, L, alpha);
     if (!h || !h->factored) return fail(SPX_ERR_ARG, "spx_get_factor: call spx_factor first");
     const int nh = h->nmodels * h->H;
     if (draw < 0 || draw >= nh) return fail(SPX_ERR_ARG, "spx_get_factor: draw out of range");
@@ -708,6 +661,7 @@ int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* al
 
 int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, double* out)
 {
+    if (h && h->multi) return spx_multi_get_cross_cov(h->multi, draw, c0, nc, out);
     if (!h || !out || !h->factored || !h->have_cand)
         return fail(SPX_ERR_ARG, "spx_get_cross_cov: need spx_factor and candidates");
     const int nh = h->nmodels * h->H;
@@ -739,6 +693,7 @@ int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, doubl
 int spx_gp_logprob(spx_handle* h, double* out)
 {
     if (!h || !out) return fail(SPX_ERR_ARG, "spx_gp_logprob: null");
+    if (h->multi) return spx_multi_gp_logprob(h->multi, out);
     int rc = do_factor(h, true, true);   // K(X,X), Cholesky, forward solve -- no inverse
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
@@ -788,6 +743,7 @@ int spx_ei_per_sec_grid(spx_handle* h, const double* comp, const double* vals, c
 int spx_sobol_grid(spx_handle* h, const uint32_t* dirs, int32_t dim_max, int32_t dim, int64_t n,
                    int64_t skip, double* grid_out, int32_t as_candidates, double* kernel_ms)
 {
+    if (h && h->multi) return spx_multi_sobol_grid(h->multi, dirs, dim_max, dim, n, skip, grid_out, as_candidates, kernel_ms);
     if (!h || !dirs || dim < 1 || dim > dim_max || n < 1)
         return fail(SPX_ERR_ARG, "spx_sobol_grid: bad arguments (dim=%d of %d, n=%lld)", dim, dim_max, (long long)n);
     if (skip + n - 2 >= (1ll << 30) || skip < -(1ll << 40))
@@ -822,57 +778,82 @@ int spx_sobol_grid(spx_handle* h, const uint32_t* dirs, int32_t dim_max, int32_t
     return SPX_OK;
 }
 
-int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad)
+int spx_ei_grad_batch(spx_handle* h, const double* points, int32_t P, double* neg_ei, double* grad)
 {
-    if (!h || !point || !neg_ei_sum || !grad) return fail(SPX_ERR_ARG, "spx_ei_grad: null argument");
-    if (!h->factored) return fail(SPX_ERR_ARG, "spx_ei_grad: call spx_factor (or spx_ei_grid) first");
-    if (h->S > 0) return fail(SPX_ERR_ARG, "spx_ei_grad: not available with fantasies set");
+    if (!h || !points || !neg_ei || !grad || P < 1) return fail(SPX_ERR_ARG, "spx_ei_grad_batch: bad argument");
+    if (h->multi) return spx_multi_ei_grad_batch(h->multi, points, P, neg_ei, grad);
+    if (!h->factored) return fail(SPX_ERR_ARG, "spx_ei_grad_batch: call spx_factor (or spx_ei_grid) first");
+    const int S = h->S;
+    const bool per_sec = (h->nmodels == 2);   // a time model was factored: EI per second (GPEIperSecChooser.py:349-434)
+    if (S > 0 && per_sec)
+        return fail(SPX_ERR_ARG, "spx_ei_grad_batch: fantasies with a time model are not defined "
+                    "(the reference's per-second refinement ignores pending jobs)");
     int rc = ensure_init(h);
     if (rc) return rc;
     const int H = h->H, D = h->D, Dp = h->Dp, Np = h->Np;
     const int64_t N = h->N;
-    if ((rc = h->pt_x.reserve((size_t)D * 8))) return rc;
-    if ((rc = h->pt_k.reserve((size_t)H * Np * 8))) return rc;
-    if ((rc = h->pt_dk.reserve((size_t)H * Np * 8))) return rc;
-    if ((rc = h->pt_t.reserve((size_t)H * Np * 8))) return rc;
-    if ((rc = h->pt_z.reserve((size_t)H * Np * 8))) return rc;
-    if ((rc = h->pt_out.reserve((size_t)H * (1 + D) * 8))) return rc;
-    const bool per_sec = (h->nmodels == 2);   // a time model was factored: EI per second (GPEIperSecChooser.py:349-434)
+    const size_t vec = (size_t)H * P * Np * 8;
+    if ((rc = h->pt_x.reserve((size_t)P * D * 8))) return rc;
+    if ((rc = h->pt_k.reserve(vec))) return rc;
+    if ((rc = h->pt_dk.reserve(vec))) return rc;
+    if ((rc = h->pt_t.reserve(vec))) return rc;
+    if ((rc = h->pt_z.reserve(vec))) return rc;
+    if ((rc = h->pt_out.reserve((size_t)H * P * (1 + D) * 8))) return rc;
     if (per_sec) {
-        if ((rc = h->pt_kt.reserve((size_t)H * Np * 8))) return rc;
-        if ((rc = h->pt_dkt.reserve((size_t)H * Np * 8))) return rc;
+        if ((rc = h->pt_kt.reserve(vec))) return rc;
+        if ((rc = h->pt_dkt.reserve(vec))) return rc;
     }
     hipStream_t s = h->stream;
-    HIPCHK(hipMemcpyAsync(h->pt_x.p, point, (size_t)D * 8, hipMemcpyHostToDevice, s));
+    if (S > 0) {
+        if ((rc = h->pt_u.reserve(vec))) return rc;
+        if (!h->alphaS_valid) {   // alpha_s = W^T Gamma_s = K^-1 (fant_s - mean) for every fantasy column (:501-502)
+            if ((rc = h->alphaS.reserve((size_t)H * S * Np * 8))) return rc;
+            launch_trimvT_multi(s, h->WT.d(), h->gammaS.d(), h->alphaS.d(), Np, H, S);
+            h->alphaS_valid = true;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(h->pt_x.p, points, (size_t)P * D * 8, hipMemcpyHostToDevice, s));
     launch_point_cov(s, h->Xs.d(), h->s1.d(), h->hyp.d(), h->htab.d(), h->pt_x.d(), h->pt_k.d(), h->pt_dk.d(),
-                     (int)N, Np, D, Dp, H);
-    launch_gemv_lower(s, h->WT.d(), h->pt_k.d(), h->pt_t.d(), Np, H);       // t = W k
-    launch_alpha(s, h->WT.d(), h->pt_t.d(), h->pt_z.d(), Np, H);            // z = W^T t = K^-1 k
+                     (int)N, Np, D, Dp, H, P);
+    launch_trimv_multi(s, h->WT.d(), h->pt_k.d(), h->pt_t.d(), Np, H, P);        // t = W k
+    launch_trimvT_multi(s, h->WT.d(), h->pt_t.d(), h->pt_z.d(), Np, H, P);       // z = W^T t = K^-1 k
     if (per_sec)   // k and dk/dr2 of the log-duration GP (table rows H..2H-1)
         launch_point_cov(s, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np,
                          h->hyp.d() + (size_t)H * (3 + D), h->htab.d() + (size_t)H * SPX_HT, h->pt_x.d(),
-                         h->pt_kt.d(), h->pt_dkt.d(), (int)N, Np, D, Dp, H);
+                         h->pt_kt.d(), h->pt_dkt.d(), (int)N, Np, D, Dp, H, P);
     launch_point_finish(s, h->Xs.d(), h->hyp.d(), h->htab.d(), h->alpha.d(), h->pt_k.d(), h->pt_dk.d(),
-                        h->pt_t.d(), h->pt_z.d(), h->pt_x.d(), h->best, h->pt_out.d(), (int)N, Np, D, Dp, H,
-                        per_sec ? h->pt_kt.d() : nullptr, per_sec ? h->pt_dkt.d() : nullptr);
-    std::vector<double> out((size_t)H * (1 + D));
+                        h->pt_t.d(), h->pt_z.d(), h->pt_x.d(), h->best, h->pt_out.d(), (int)N, Np, D, Dp, H, P,
+                        per_sec ? h->pt_kt.d() : nullptr, per_sec ? h->pt_dkt.d() : nullptr, S,
+                        S > 0 ? h->gammaS.d() : nullptr, S > 0 ? h->alphaS.d() : nullptr,
+                        S > 0 ? h->bests.d() : nullptr, S > 0 ? h->pt_u.d() : nullptr);
+    std::vector<double> out((size_t)H * P * (1 + D));
     HIPCHK(hipMemcpyAsync(out.data(), h->pt_out.p, out.size() * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     // sum over draws in draw order, as grad_optimize_ei_over_hypers does (:368-380)
-    double f = 0.0;
-    for (int d = 0; d < D; ++d) grad[d] = 0.0;
-    for (int i = 0; i < H; ++i) {
-        f += -out[(size_t)i * (1 + D)];
-        for (int d = 0; d < D; ++d) grad[d] = grad[d] + out[(size_t)i * (1 + D) + 1 + d];
+    for (int p = 0; p < P; ++p) {
+        double f = 0.0;
+        double* g = grad + (size_t)p * D;
+        for (int d = 0; d < D; ++d) g[d] = 0.0;
+        for (int i = 0; i < H; ++i) {
+            const double* o = &out[((size_t)i * P + p) * (1 + D)];
+            f += -o[0];
+            for (int d = 0; d < D; ++d) g[d] = g[d] + o[1 + d];
+        }
+        neg_ei[p] = f;
     }
-    *neg_ei_sum = f;
     return SPX_OK;
+}
+
+int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad)
+{
+    return spx_ei_grad_batch(h, point, 1, neg_ei_sum, grad);
 }
 
 int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n)
 {
     if (!h) return fail(SPX_ERR_ARG, "null handle");
+    if (h->multi) return spx_multi_get_timings(h->multi, ms, launches, n);
     for (int i = 0; i < n && i < ST_COUNT; ++i) {
         if (ms) ms[i] = h->st_ms[i];
         if (launches) launches[i] = h->st_n[i];

@@ -1,0 +1,125 @@
+// Internal definitions shared by spx_api.hip (single-GPU engine + C ABI) and spx_multi.hip
+// (several GPUs behind one handle).  Not installed; include/spx.h is the public surface.
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/spx.h"
+#include "common.h"
+
+std::string& spx_err_slot();            // thread-local last-error text
+int spx_fail(int code, const char* fmt, ...);
+#define fail spx_fail
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(SPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SPX_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess)
+            return fail(SPX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return SPX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    double* d() const { return (double*)p; }
+};
+
+enum Stage {
+    ST_SCALE = 0, ST_COV_SELF, ST_CHOL_DIAG, ST_CHOL_PANEL, ST_TRINV, ST_GAMMA_ALPHA,
+    ST_COV_CROSS, ST_CROSS_MEAN, ST_PREDICT_GEMM, ST_EI_FINALIZE, ST_MEAN_ARGMAX,
+    ST_FACTOR_TOTAL, ST_EI_RUN_TOTAL, ST_COUNT
+};
+struct spx_handle {
+    int device = 0;
+    bool inited = false;
+    hipStream_t stream = nullptr;    // main stream (also the only one the factorization uses)
+    hipStream_t stream2 = nullptr;   // optional producer stream (option "streams" = 2): K(X*,X) of the next
+                                     // work item is generated (VALU) while the GEMM of the current one runs (MFMA)
+    hipEvent_t ev_sync[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // whole-stage timers (factor / ei_run)
+
+    int64_t N = 0, M = 0, index_base = 0;
+    int D = 0, Dp = 0, Np = 0, H = 0;
+    bool have_obs = false, have_cand = false, have_hyp = false, have_time = false;
+    bool factored = false, ran = false, ran_moments = false;
+    int nmodels = 1;  // 1 = objective GP only, 2 = + log-duration GP
+    double best = 0.0;
+    int not_pd_draw = -1, not_pd_pivot = -1;
+    int64_t kst_budget = 512ll << 20;   // K(X*,X) staging buffer per stream (bytes)
+    int nstreams = 1;
+    int gemm_variant = 0;               // predict-GEMM variant of THIS handle (option "gemm_waves"); 0 = production
+    struct spx_multi* multi = nullptr;  // non-null: this handle fronts several per-GPU handles (spx_multi.hip)
+
+    std::vector<double> hyp_host, thyp_host;
+
+    DevBuf comp, vals, ldur, cand, hyp, htab;
+    DevBuf Xs, X2s, s1, Lm, WT, Dinv, gamma, alpha, info, lp;
+    DevBuf Cs[2], s2[2], Kst[2], part_ss[2], part_bg[2], time_m[2], ei_draw, ei_mean, mom_m, mom_v, mom_t;
+    DevBuf am_val, am_idx, am_out_val, am_out_idx, scratch;
+    // pending-experiment fantasies (spx_set_fantasies): S right-hand sides per draw
+    int S = 0;
+    DevBuf fantT, gammaS, bests, part_bgS[2];
+    DevBuf alphaS;                 // [H][S][Np] = W^T Gamma_s, built on the first spx_ei_grad_batch after spx_set_fantasies
+    bool alphaS_valid = false;
+    DevBuf pt_x, pt_k, pt_dk, pt_t, pt_z, pt_out, pt_kt, pt_dkt, pt_u;   // spx_ei_grad_batch work vectors
+    DevBuf rec_send, rec_recv, rec_out;   // {best mean EI, global index} records of the multi-GPU all-gather
+    DevBuf sobol_dirs, sobol_out;                                   // spx_sobol_grid
+    DevBuf rhs;                                                     // spx_gp_logprob: [H][64][Np] right-hand-side rows
+
+    double best_val = 0.0;
+    int64_t best_idx = -1;
+
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int stage; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    double st_ms[ST_COUNT] = {0};
+    int64_t st_n[ST_COUNT] = {0};
+};
+
+
+// ---- several GPUs behind one handle (spx_multi.hip) --------------------------------------------
+struct spx_multi;
+void spx_multi_destroy(spx_multi* m);
+int spx_multi_set_option(spx_multi* m, const char* name, int64_t value);
+int spx_multi_set_observations(spx_multi* m, const double* comp, const double* vals, int64_t N, int32_t D);
+int spx_multi_set_candidates(spx_multi* m, const double* cand, int64_t M, int32_t D, int64_t index_base);
+int spx_multi_set_hypers(spx_multi* m, const double* hypers, int32_t H);
+int spx_multi_set_time_model(spx_multi* m, const double* log_durs, const double* time_hypers);
+int spx_multi_factor(spx_multi* m);
+int spx_multi_set_fantasies(spx_multi* m, const double* fant, const double* bests, int32_t S);
+int spx_multi_ei_run(spx_multi* m, int32_t flags);
+int spx_multi_get_best(spx_multi* m, int64_t* best_idx, double* best_val);
+int spx_multi_get_ei_mean(spx_multi* m, double* out);
+int spx_multi_get_ei_draws(spx_multi* m, double* out);
+int spx_multi_get_moments(spx_multi* m, int32_t draw, double* func_m, double* func_v);
+int spx_multi_get_time_mean(spx_multi* m, int32_t draw, double* out);
+int spx_multi_get_factor(spx_multi* m, int32_t draw, double* K, double* L, double* alpha);
+int spx_multi_get_cross_cov(spx_multi* m, int32_t draw, int64_t c0, int64_t nc, double* out);
+int spx_multi_gp_logprob(spx_multi* m, double* out);
+int spx_multi_ei_grad_batch(spx_multi* m, const double* points, int32_t P, double* neg_ei, double* grad);
+int spx_multi_sobol_grid(spx_multi* m, const uint32_t* dirs, int32_t dim_max, int32_t dim, int64_t n,
+                         int64_t skip, double* grid_out, int32_t as_candidates, double* kernel_ms);
+int spx_multi_not_pd_info(spx_multi* m, int32_t* draw, int32_t* pivot);
+int spx_multi_get_timings(spx_multi* m, double* ms, int64_t* launches, int n);
+int spx_multi_info(spx_multi* m, int32_t* n_dev, int32_t* transport, int32_t* device_ids, int32_t cap);
+// single-GPU pieces the multi layer needs
+int spx_ensure_init(spx_handle* h);

@@ -34,6 +34,8 @@ _c_int32_p = ctypes.POINTER(ctypes.c_int32)
 _vp = ctypes.c_void_p
 ABI = {
     "spx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "spx_create_multi": (ctypes.c_int, [_c_int32_p, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    "spx_multi_query": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p, _c_int32_p, ctypes.c_int32]),
     "spx_destroy": (None, [_vp]),
     "spx_last_error": (ctypes.c_char_p, []),
     "spx_version": (ctypes.c_int, []),
@@ -61,6 +63,7 @@ ABI = {
     "spx_get_time_mean": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p]),
     "spx_gp_logprob": (ctypes.c_int, [_vp, _c_double_p]),
     "spx_ei_grad": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p]),
+    "spx_ei_grad_batch": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int32, _c_double_p, _c_double_p]),
     "spx_sobol_grid": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32, ctypes.c_int32,
                                       ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_int32, _c_double_p]),
     "spx_not_pd_info": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p]),
@@ -113,21 +116,43 @@ class SpxError(RuntimeError):
     pass
 
 
+TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "host"}
+
+
 class Engine(object):
-    """One GPU, one handle.  Mirrors the resident-data C API.
+    """One handle of libspx: one GPU (``device=``) or several GPUs of this node behind the same
+    calls (``devices=[...]`` -> spx_create_multi: candidates sharded over the devices, one RCCL
+    all-gather of {best EI, index} records per EI pass).  Mirrors the resident-data C API.
 
     Typical use (what the choosers do, GPEIOptChooser.py:331-341 + :294):
 
         eng = Engine(device=0)
-        best, ei_mean, overall_ei = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        best, value, ei_mean, overall_ei = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
     """
 
-    def __init__(self, device=0, lib=None):
+    def __init__(self, device=0, lib=None, devices=None):
         self._lib = load_library(lib)
         self._h = _vp()
-        self._check(self._lib.spx_create(int(device), ctypes.byref(self._h)))
-        self.device = int(device)
+        if devices is not None:
+            devs = [int(d) for d in devices]
+            if not devs:
+                raise ValueError("Engine needs at least one device")
+            arr = (ctypes.c_int32 * len(devs))(*devs)
+            self._check(self._lib.spx_create_multi(arr, len(devs), ctypes.byref(self._h)))
+            self.devices = devs
+            self.device = devs[0]
+        else:
+            self._check(self._lib.spx_create(int(device), ctypes.byref(self._h)))
+            self.device = int(device)
+            self.devices = [self.device]
         self.N = self.M = self.D = self.H = 0
+
+    def transport(self):
+        """"none" (one GPU), "rccl" (ncclAllGather over the devices) or "host" (repeated device
+        ids: records staged through host memory)."""
+        t = ctypes.c_int32(0)
+        self._check(self._lib.spx_multi_query(self._h, None, ctypes.byref(t), None, 0))
+        return TRANSPORT_NAMES.get(int(t.value), "?")
 
     # -- plumbing ---------------------------------------------------------
     def _check(self, rc):
@@ -312,6 +337,18 @@ class Engine(object):
         self._check(self._lib.spx_ei_grad(self._h, _dp(x), ctypes.byref(f), _dp(g)))
         return float(f.value), g
 
+    def ei_grad_batch(self, points):
+        """The same objective at P points in one call: (f[P], grad[P, D]).  A point's result does
+        not depend on which other points share the call.  With fantasies set the objective is the
+        pending branch of the reference (GPEIOptChooser.py:441-525)."""
+        x = _f64(np.atleast_2d(points))
+        if x.ndim != 2 or x.shape[1] != self.D:
+            raise ValueError("points must be (P, D)")
+        f = np.empty(x.shape[0])
+        g = np.empty(x.shape)
+        self._check(self._lib.spx_ei_grad_batch(self._h, _dp(x), x.shape[0], _dp(f), _dp(g)))
+        return f, g
+
     def sobol_grid(self, dirs, dim, n, skip, fetch=True, as_candidates=False):
         """The reference's Sobol grid, generated on the GPU: returns (grid, kernel_ms) with
         grid (n, dim) == np.transpose(i4_sobol_generate(dim, n, skip)) bit for bit
@@ -355,119 +392,11 @@ def device_count(lib=None):
     return n if n > 0 else 0
 
 
-class MultiEngine(object):
-    """Several GPUs driven from ONE process (the unmodified Spearmint driver is a
-    single process): candidates are sharded contiguously over `devices`, each shard
-    is scored by its own Engine on its own host thread (ctypes releases the GIL
-    while libspx runs), observations / hyper draws are replicated, and the per-shard
-    (best value, global index) records are combined with the numpy argmax rule --
-    the same decomposition as the one-process-per-GPU path of bench.py, minus the
-    collective (the records already live in one address space).
-
-    Same surface as Engine for what the choosers call."""
+class MultiEngine(Engine):
+    """Several GPUs driven from ONE process (the unmodified Spearmint driver is a single
+    process): an Engine over spx_create_multi.  Sharding, the per-device host threads and the
+    RCCL all-gather all live inside libspx (csrc/spx_multi.hip); this class only keeps the
+    round-1 constructor signature."""
 
     def __init__(self, devices, lib=None):
-        self.devices = [int(d) for d in devices]
-        if not self.devices:
-            raise ValueError("MultiEngine needs at least one device")
-        self.engines = [Engine(d, lib) for d in self.devices]
-        self.N = self.M = self.D = self.H = 0
-        self._bounds = []
-
-    # the single-point / single-stream calls go to the first engine
-    def __getattr__(self, name):
-        if name in ("gp_logprob", "ei_grad", "get_factor", "not_pd_info", "timings", "get_cross_cov"):
-            return getattr(self.engines[0], name)
-        raise AttributeError(name)
-
-    def close(self):
-        for e in self.engines:
-            e.close()
-
-    def _each(self, fn):
-        import threading
-        out = [None] * len(self.engines)
-        err = []
-
-        def run(i):
-            try:
-                out[i] = fn(i, self.engines[i])
-            except BaseException as ex:  # re-raised in the caller's thread
-                err.append(ex)
-        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(self.engines))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if err:
-            raise err[0]
-        return out
-
-    def set_observations(self, comp, vals):
-        comp = _f64(comp); vals = _f64(vals).ravel()
-        self.N, self.D = comp.shape
-        self._each(lambda i, e: e.set_observations(comp, vals))
-
-    def set_hypers(self, hypers):
-        hypers = _f64(np.atleast_2d(hypers))
-        self.H = hypers.shape[0]
-        self._each(lambda i, e: e.set_hypers(hypers))
-
-    def set_time_model(self, log_durs, time_hypers):
-        self._each(lambda i, e: e.set_time_model(log_durs, time_hypers))
-
-    def set_option(self, name, value):
-        self._each(lambda i, e: e.set_option(name, value))
-
-    def set_candidates(self, cand, index_base=0):
-        from .dist import shard_bounds
-        cand = _f64(cand)
-        self.M = cand.shape[0]
-        P = min(len(self.engines), self.M)
-        self._bounds = [shard_bounds(self.M, P, r) for r in range(P)]
-        self._base = int(index_base)
-        self._each(lambda i, e: e.set_candidates(cand[self._bounds[i][0]:self._bounds[i][1]],
-                                                 index_base + self._bounds[i][0]) if i < P else None)
-
-    def factor(self):
-        self._each(lambda i, e: e.factor())
-
-    def set_fantasies(self, fant, bests):
-        self._each(lambda i, e: e.set_fantasies(fant, bests))
-
-    def ei_run(self, flags=0):
-        self._each(lambda i, e: e.ei_run(flags) if i < len(self._bounds) else None)
-
-    def best(self):
-        from .dist import pick_best
-        recs = [list(self.engines[i].best()[::-1]) for i in range(len(self._bounds))]
-        return pick_best(recs)
-
-    def ei_mean(self):
-        return np.concatenate([self.engines[i].ei_mean() for i in range(len(self._bounds))])
-
-    def ei_draws(self):
-        return np.vstack([self.engines[i].ei_draws() for i in range(len(self._bounds))])
-
-    def get_time_mean(self, draw):
-        return np.concatenate([self.engines[i].get_time_mean(draw) for i in range(len(self._bounds))])
-
-    def ei_grid(self, comp, vals, cand, hypers, want_mean=True, want_draws=False, flags=0):
-        self.set_observations(comp, vals)
-        self.set_candidates(cand)
-        self.set_hypers(hypers)
-        self.factor()
-        self.ei_run(flags)
-        idx, val = self.best()
-        return idx, val, (self.ei_mean() if want_mean else None), (self.ei_draws() if want_draws else None)
-
-    def ei_per_sec_grid(self, comp, vals, log_durs, cand, hypers, time_hypers,
-                        want_mean=True, want_draws=False, flags=0):
-        self.set_observations(comp, vals)
-        self.set_candidates(cand)
-        self.set_hypers(hypers)
-        self.set_time_model(log_durs, time_hypers)
-        self.factor()
-        self.ei_run(flags | FLAG_PER_SEC)
-        idx, val = self.best()
-        return idx, val, (self.ei_mean() if want_mean else None), (self.ei_draws() if want_draws else None)
+        Engine.__init__(self, lib=lib, devices=list(devices))

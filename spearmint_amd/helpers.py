@@ -31,5 +31,11 @@ def pickle_atomically(obj, path):
 
 
 def unpickle(path):
+    """Load a state pickle.  A file written by the Python-2 reference holds numpy arrays pickled as
+    byte strings; Python 3 can only read those with encoding="latin1"."""
     with open(path, "rb") as fh:
-        return pickle.load(fh)
+        try:
+            return pickle.load(fh)
+        except UnicodeDecodeError:
+            fh.seek(0)
+            return pickle.load(fh, encoding="latin1")

@@ -65,6 +65,7 @@ class OracleEngine(object):
     def ei_grid(self, comp, vals, cand, hypers, want_mean=True, want_draws=False, flags=0):
         ei = orc.ei_over_hypers(comp, cand, vals, hypers)
         self._last_comp, self._last_vals, self._last_rows = comp, vals, np.atleast_2d(hypers)
+        self._last_time, self.fant = None, None
         mean = np.mean(ei, axis=1)
         idx = int(np.argmax(mean))
         self.calls.append(("ei_grid", cand.shape[0], np.atleast_2d(hypers).shape[0]))
@@ -75,18 +76,32 @@ class OracleEngine(object):
         self.calls.append(("sobol_grid", int(dim), int(n), int(skip)))
         return np.ascontiguousarray(sobol_oracle.i4_sobol_generate(dim, n, skip, dirs).T), 0.0
 
+    def ei_grad_batch(self, points):
+        """The refinement objective from the oracle's restatement of grad_optimize_ei_over_hypers,
+        against whatever the last EI pass left "resident" (plain, fantasies, or per second)."""
+        points = np.atleast_2d(points)
+        f = np.zeros(points.shape[0]); g = np.zeros(points.shape)
+        for i, x in enumerate(points):
+            if self.fant is not None:
+                for h in range(self.hypers.shape[0]):
+                    e, gr = orc.grad_optimize_ei_fantasies(x, self.comp, self.hypers[h], self.fant[h], self.bests[h])
+                    f[i] += e; g[i] = g[i] + gr
+            elif getattr(self, "_last_time", None) is not None:
+                f[i], g[i] = orc.grad_optimize_ei_over_hypers(x, self._last_comp, self._last_vals, self._last_rows,
+                                                              log_durs=self._last_time[0], time_hypers=self._last_time[1])
+            else:
+                f[i], g[i] = orc.grad_optimize_ei_over_hypers(x, self._last_comp, self._last_vals, self._last_rows)
+        return f, g
+
     def ei_grad(self, x):
-        from spearmint_amd import hostgp
-        total, grad = 0.0, np.zeros(len(x))
-        for h in self._last_rows:
-            e, g = hostgp.PointModel(self._last_comp, self._last_vals, (h[0], h[1], h[2], h[3:])).neg_ei_and_grad(x)
-            total += e
-            grad = grad + g
-        return total, grad
+        f, g = self.ei_grad_batch(np.asarray(x)[None, :])
+        return float(f[0]), g[0]
 
     def ei_per_sec_grid(self, comp, vals, log_durs, cand, hypers, time_hypers,
                         want_mean=True, want_draws=False, flags=0):
         ei = orc.ei_per_s_over_hypers(comp, cand, vals, log_durs, hypers, time_hypers)
+        self._last_comp, self._last_vals, self._last_rows = comp, vals, np.atleast_2d(hypers)
+        self._last_time, self.fant = (log_durs, np.atleast_2d(time_hypers)), None
         mean = np.mean(ei, axis=1)
         idx = int(np.argmax(mean))
         self.calls.append(("ei_per_sec_grid", cand.shape[0], np.atleast_2d(hypers).shape[0]))

@@ -218,3 +218,89 @@ def test_speculative_sampler_is_the_same_markov_chain(golden_dir):
     for k in range(1, g["compwise"].shape[0]):
         x = util.slice_sample_batched(x, many, compwise=True)
         assert np.allclose(x, g["compwise"][k], rtol=1e-9)
+
+
+# ---- batched local refinement (spearmint_amd/refine.py) ------------------------------------
+def test_lbfgs_many_equals_serial_scipy():
+    """Every L-BFGS-B instance fed from batched objective calls returns exactly what a serial
+    fmin_l_bfgs_b run on the same objective returns."""
+    import scipy.optimize as spo
+    from spearmint_amd import refine
+    rs = np.random.RandomState(0)
+    A = rs.randn(5, 5); A = A @ A.T + np.eye(5)
+    c = rs.rand(5)
+    batches = []
+
+    def f_one(x):
+        r = x - c
+        return float(r @ A @ r + np.sum(np.cos(3 * x))), 2 * A @ r - 3 * np.sin(3 * x)
+
+    def f_many(X):
+        batches.append(len(X))
+        fs, gs = zip(*[f_one(x) for x in X])
+        return np.array(fs), np.array(gs)
+
+    pts = rs.rand(7, 5)
+    bounds = [(0, 1)] * 5
+    got = refine.lbfgs_many(f_many, pts, bounds)
+    for i in range(7):
+        ref = spo.fmin_l_bfgs_b(f_one, pts[i].copy(), bounds=bounds, disp=0)[0]
+        assert np.array_equal(got[i], ref)
+    assert batches[0] == 7 and min(batches) >= 1 and len(batches) < sum(batches)   # really batched
+    assert refine.lbfgs_many(f_many, np.zeros((0, 5)), bounds).shape == (0, 5)
+
+
+def test_lbfgs_many_propagates_errors():
+    from spearmint_amd import refine
+
+    def boom(X):
+        raise RuntimeError("objective failed")
+    with pytest.raises(RuntimeError):
+        refine.lbfgs_many(boom, np.random.rand(3, 2), [(0, 1)] * 2)
+
+
+def test_opt_next_with_batched_refinement_matches_reference(golden_dir, tmp_path):
+    """gpu_refine=1 routes the grid_subset L-BFGS-B problems through refine.lbfgs_many +
+    engine.ei_grad_batch (here the oracle's restatement of grad_optimize_ei_over_hypers): the
+    proposal must still be the reference's."""
+    g = _g(golden_dir, "chooser_next.npz")
+    ch = GPEIOptChooser.init(str(tmp_path), "mcmc_iters=4,burnin=6,grid_subset=5,use_multiprocessing=0,gpu_refine=1")
+    ch._eng = OracleEngine()
+    npr.seed(int(g["opt_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert isinstance(job, tuple) == bool(int(g["opt_is_new"]))
+    if isinstance(job, tuple):
+        assert job[0] == int(g["opt_index"]) and np.allclose(job[1], g["opt_point"], atol=1e-6)
+
+
+def test_opt_next_pending_with_batched_refinement_matches_reference(golden_dir, tmp_path):
+    g = _g(golden_dir, "chooser_next_pending.npz")
+    ch = GPEIOptChooser.init(str(tmp_path), "mcmc_iters=3,burnin=4,grid_subset=3,pending_samples=8,"
+                                            "use_multiprocessing=0,gpu_refine=1")
+    ch._eng = OracleEngine()
+    npr.seed(int(g["o_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    if int(g["o_is_new"]):
+        assert isinstance(job, tuple) and job[0] == int(g["o_index"]) and np.allclose(job[1], g["o_point"], atol=1e-6)
+    else:
+        assert job == int(g["o_index"])
+
+
+def test_pending_samples_range_is_checked(tmp_path):
+    with pytest.raises(ValueError):
+        GPEIChooser.init(str(tmp_path), "pending_samples=5000")
+    GPEIChooser.init(str(tmp_path), "pending_samples=300")     # > 128 is fine now
+
+
+def test_unpickle_reads_python2_state(tmp_path):
+    """A state file written by the Python-2 reference holds numpy arrays as byte strings."""
+    from spearmint_amd.helpers import unpickle
+    # protocol-2 pickle of {'ls': ndarray} as Python 2 / numpy 1.x writes it (bytes payload, 'latin1' only)
+    py2 = (b"\x80\x02}q\x00U\x02lsq\x01cnumpy.core.multiarray\n_reconstruct\nq\x02cnumpy\nndarray\nq\x03K\x00\x85q\x04U\x01b"
+           b"q\x05\x87q\x06Rq\x07(K\x01K\x02\x85q\x08cnumpy\ndtype\nq\tU\x02f8q\nK\x00K\x01\x87q\x0bRq\x0c(K\x03U\x01<q\rNNNJ"
+           b"\xff\xff\xff\xffJ\xff\xff\xff\xffK\x00tq\x0eb\x89U\x10\x00\x00\x00\x00\x00\x00\xf0?\x9a\x99\x99\x99\x99\x99\xb9?"
+           b"q\x0ftq\x10bs.")
+    p = tmp_path / "state.pkl"
+    p.write_bytes(py2)
+    st = unpickle(str(p))
+    assert np.allclose(st["ls"], [1.0, 0.1])
