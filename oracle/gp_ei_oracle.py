@@ -173,6 +173,26 @@ def compute_ei_pending(comp, pend, cand, vals, hyper, randn_ps):
     return np.mean(ei, axis=1)
 
 
+def fantasize(comp, pend, vals, hyper, randn_ps):
+    """First half of the pending branch (GPEIChooser.py:213-249): the S joint fantasy outcomes of
+    the P pending jobs.  Returns fant_vals ((N+P) x S) and bests (S,)."""
+    mean, noise, amp2, ls = unpack_hyper(hyper)
+    n = comp.shape[0]
+    comp_pend = np.concatenate((comp, pend))
+    cp_chol = spla.cholesky(cov(amp2, ls, comp_pend) + noise * np.eye(comp_pend.shape[0]), lower=True)
+    pend_cross = cov(amp2, ls, comp, pend)
+    pend_kappa = cov(amp2, ls, pend)
+    obsv_chol = cp_chol[:n, :n]
+    alpha = spla.cho_solve((obsv_chol, True), vals - mean)
+    beta = spla.cho_solve((obsv_chol, True), pend_cross)
+    pend_m = np.dot(pend_cross.T, alpha) + mean
+    pend_K = pend_kappa - np.dot(pend_cross.T, beta)
+    pend_chol = spla.cholesky(pend_K, lower=True)
+    pend_fant = np.dot(pend_chol, randn_ps) + pend_m[:, None]
+    fant_vals = np.concatenate((np.tile(vals[:, np.newaxis], (1, randn_ps.shape[1])), pend_fant))
+    return fant_vals, np.min(fant_vals, axis=0)
+
+
 def compute_ei_fantasies(comp_pend, cand, hyper, fant_vals, bests):
     """Second half of the pending branch (GPEIChooser.py:251-266) for given
     fantasy values: EI of every candidate against every fantasy, averaged."""

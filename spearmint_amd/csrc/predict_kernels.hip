@@ -293,7 +293,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
 
 // Variants (spx_set_option "gemm_waves", per handle): 0 / 14 = production (4 waves, LDS-DMA staging,
 // measured fastest), 4 / 8 = 4 / 8 waves with register staging, 18 = 8 waves with LDS-DMA, 24 = LDS-DMA
-// with three 8-row buffers and two tiles in flight.  All of these produce identical results.  The
+// with three 8-row buffers and two tiles in flight.  They agree to rounding (the 8-wave kernels sum the
+// row groups of the epilogue in another order).  The
 // timing-only ablations 41..44 (WRONG results, for performance analysis) exist only in a library
 // built with -DSPX_ABLATIONS (make ABLATIONS=1); the shipped library rejects them.
 bool predict_gemm_variant_ok(int v)

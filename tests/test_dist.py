@@ -80,3 +80,19 @@ def test_allreduce_best_gloo_world2():
 
 def test_allreduce_without_group_is_identity():
     assert sd.allreduce_best(1.5, 42) == (42, 1.5)
+
+
+def test_strong_scaling_grid_does_not_depend_on_world_size():
+    """bench.py's full-size C4 / C5 grids are defined in seeded blocks: any split over ranks
+    concatenates to the same rows (so every --gpus N must report the same best_index)."""
+    import bench
+    cfg = dict(bench.STRONG["c5"]); cfg["M"] = 3 * bench.STRONG_BLOCK + 1234
+    _, comp, vals, _ = bench.strong_problem(dict(cfg, N=32))
+    full = bench.strong_rows(cfg, comp, vals, 0, cfg["M"])
+    assert full.shape == (cfg["M"], cfg["D"]) and np.all((full >= 0) & (full <= 1))
+    for world in (2, 3, 8):
+        parts = [bench.strong_rows(cfg, comp, vals, *sd.shard_bounds(cfg["M"], world, r)) for r in range(world)]
+        assert np.array_equal(np.vstack(parts), full)
+    # the incumbent's jittered copies open the grid
+    inc = comp[np.argmin(vals)]
+    assert np.max(np.abs(full[:10] - inc)) < 0.01

@@ -1,0 +1,279 @@
+"""Multi-GPU pieces on the one-GPU test box:
+
+ * spx_create_multi -- one handle over several devices, the RCCL all-gather of {EI, index} records
+   inside libspx.  devices=[0] builds a real RCCL communicator of size 1 (ncclCommInitAll +
+   ncclAllGather run on the hardware); devices=[0, 0, 0] puts three engines on the one GPU
+   (repeated ids cannot form a communicator, so the records are staged through the host) and
+   exercises sharding, the per-device threads and the final reduction.  Both must be bit-identical
+   to a single engine.
+ * bench.py with two ranks (one process per rank, gloo, both on GPU 0): the winner equals a
+   one-rank run over the concatenated candidates, for the weak headline and for the strong-scaling
+   c4 / c5 sub-records.
+ * spx_ei_grad_batch against the reference's own refinement objective (tests/golden/ei_grad.npz)
+   and the oracle's restatement of it.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bench
+from oracle import gp_ei_oracle as orc
+from spearmint_amd.engine import Engine, FLAG_PER_SEC, MultiEngine
+from spearmint_amd.synthetic import synthetic_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+# ---- spx_create_multi -----------------------------------------------------------------------------
+@pytest.mark.timeout(300)
+def test_rccl_communicator_of_one_device(eng):
+    comp, cand, vals, hypers = synthetic_problem(200, 3001, 5, 4, 61)
+    one = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    me = Engine(devices=[0])
+    try:
+        assert me.transport() == "rccl"
+        many = me.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        assert many[0] == one[0] and many[1] == one[1]
+        assert np.array_equal(many[2], one[2]) and np.array_equal(many[3], one[3])
+    finally:
+        me.close()
+
+
+def test_three_engines_on_one_gpu_match_single(eng):
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(200, 3001, 5, 4, 61, per_sec=True)
+    one = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    ops = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+    me = MultiEngine([0, 0, 0])
+    try:
+        assert me.transport() == "host" and eng.transport() == "none"
+        many = me.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        assert many[0] == one[0] and many[1] == one[1]
+        assert np.array_equal(many[2], one[2]) and np.array_equal(many[3], one[3])
+        mps = me.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+        assert mps[0] == ops[0] and np.array_equal(mps[3], ops[3])
+        # ties across shards go to the lowest global index; NaN wins
+        c2 = cand.copy(); c2[2500] = c2[10]
+        a = eng.ei_grid(comp, vals, c2, hypers); b = me.ei_grid(comp, vals, c2, hypers)
+        assert a[0] == b[0] and np.array_equal(a[2], b[2])
+        c2[2900, 0] = np.nan
+        a = eng.ei_grid(comp, vals, c2, hypers); b = me.ei_grid(comp, vals, c2, hypers)
+        assert a[0] == b[0] == 2900
+        # fewer candidates than devices
+        a = eng.ei_grid(comp, vals, cand[:2], hypers); b = me.ei_grid(comp, vals, cand[:2], hypers)
+        assert a[0] == b[0] and np.array_equal(a[2], b[2])
+        # building blocks across shards
+        me.ei_grid(comp, vals, cand, hypers); eng.ei_grid(comp, vals, cand, hypers)
+        assert np.array_equal(me.get_cross_cov(1, 900, 1500), eng.get_cross_cov(1, 900, 1500))
+        assert np.array_equal(me.get_factor(2)[1], eng.get_factor(2)[1])
+    finally:
+        me.close()
+
+
+def test_multi_shards_loglikelihood_draws_and_refinement_points(eng):
+    comp, cand, vals, hypers = synthetic_problem(330, 400, 5, 7, 62)
+    hypers[4, 2] = -1.0                               # one non-PD draw
+    me = MultiEngine([0, 0, 0])
+    try:
+        for e in (eng, me):
+            e.set_observations(comp, vals); e.set_hypers(hypers)
+        ref = eng.gp_logprob()
+        got = me.gp_logprob()                          # 7 draws over 3 engines: 3 + 2 + 2
+        assert np.array_equal(got, ref) and got[4] == -np.inf
+        assert me.not_pd_info()[0] == 4 == eng.not_pd_info()[0]
+        with pytest.raises(np.linalg.LinAlgError):
+            me.gp_logprob(raise_not_pd=True)
+        # after a sharded log-likelihood the EI path must see the full hyper set again
+        hypers[4, 2] = 1.0
+        for e in (eng, me):
+            e.set_hypers(hypers)
+        lp = me.gp_logprob()
+        assert np.array_equal(lp, eng.gp_logprob())
+        me.set_candidates(cand); eng.set_candidates(cand)
+        me.factor(); eng.factor(); me.ei_run(); eng.ei_run()
+        assert me.best() == eng.best() and np.array_equal(me.ei_draws(), eng.ei_draws())
+        pts = np.random.RandomState(3).rand(11, 5)
+        f1, g1 = eng.ei_grad_batch(pts)
+        f3, g3 = me.ei_grad_batch(pts)                 # 11 points over 3 engines
+        assert np.array_equal(f1, f3) and np.array_equal(g1, g3)
+    finally:
+        me.close()
+
+
+def test_chooser_with_ndev_uses_the_multi_handle(golden_dir, tmp_path):
+    import numpy.random as npr
+    from spearmint_amd.chooser import GPEIOptChooser
+    g = np.load(os.path.join(golden_dir, "chooser_next.npz"))
+    ch = GPEIOptChooser.init(str(tmp_path), "mcmc_iters=4,burnin=6,grid_subset=5,use_multiprocessing=0,"
+                                            "gpu_refine=1,gpu_logprob=1,ndev=1")
+    ch._eng = MultiEngine([0, 0])
+    npr.seed(int(g["opt_seed"]))
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert isinstance(job, tuple) and job[0] == int(g["opt_index"])
+    assert np.allclose(job[1], g["opt_point"], atol=1e-5)
+
+
+# ---- bench.py, two ranks on the one GPU -----------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_equals_one_rank_over_concatenated_candidates(eng):
+    env = dict(os.environ, SPX_BENCH_BACKEND="gloo", SPX_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c2", "--no-cpu-baseline",
+           "--extra-steps", "1", "--c4-candidates", "30000", "--c5-candidates", "20000"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=850)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    line = [l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["c4"]["scaling"] == "strong"
+    # weak headline: rank r scored its own shard; one rank over [shard0; shard1] must pick the same row
+    w = bench.WORKLOADS["c2"]
+    _, comp, vals, hypers, s0 = bench.weak_problem(w, 0)
+    s1 = bench.weak_problem(w, 1)[4]
+    idx, val, _, _ = eng.ei_grid(comp, vals, np.vstack((s0, s1)), hypers)
+    assert (out["best_index"], out["best_ei"]) == (idx, val)
+    # strong sub-records: the same grid whatever the number of ranks
+    for name, M in (("c4", 30000), ("c5", 20000)):
+        cfg = dict(bench.STRONG[name]); cfg["M"] = M
+        prob, scomp, svals, shyp = bench.strong_problem(cfg)
+        rows = bench.strong_rows(cfg, scomp, svals, 0, M)
+        if cfg["per_sec"]:
+            i1, v1, _, _ = eng.ei_per_sec_grid(scomp, svals, prob[4], rows, shyp, prob[5])
+        else:
+            i1, v1, _, _ = eng.ei_grid(scomp, svals, rows, shyp)
+        assert (out[name]["best_index"], out[name]["best_ei"]) == (i1, v1)
+        assert out[name]["config"]["candidates_total"] == M and out["%s_value" % name] > 0
+
+
+# ---- spx_ei_grad_batch: the refinement objective ---------------------------------------------------
+def test_ei_grad_batch_matches_reference_golden(eng, golden_dir):
+    """Value + gradient of the reference's grad_optimize_ei_over_hypers (GPEIOptChooser.py:360-525,
+    GPEIperSecChooser.py:322-434) as dumped from the reference itself."""
+    g = np.load(os.path.join(golden_dir, "ei_grad.npz"))
+    for tag in "ab":
+        comp, vals, hypers, pts = g[tag + "_comp"], g[tag + "_vals"], g[tag + "_hypers"], g[tag + "_points"]
+        eng.ei_grid(comp, vals, pts, hypers)             # leaves observations, draws and factors resident
+        f, gr = eng.ei_grad_batch(pts)
+        assert np.allclose(f, g[tag + "_f"], rtol=1e-7, atol=1e-300)
+        assert np.allclose(gr, g[tag + "_g"], rtol=1e-6, atol=1e-9 * np.abs(g[tag + "_g"]).max())
+    # pending branch: fantasies from the oracle's restatement of the first half of the branch
+    comp, pend, vals, hypers, pts = g["p_comp"], g["p_pend"], g["p_vals"], g["p_hypers"], g["p_points"]
+    H, P = hypers.shape[0], pend.shape[0]
+    fb = [orc.fantasize(comp, pend, vals, hypers[h], g["p_randn"]) for h in range(H)]
+    eng.set_observations(np.concatenate((comp, pend)), np.concatenate((vals, np.zeros(P))))
+    eng.set_candidates(pts); eng.set_hypers(hypers); eng.factor()
+    eng.set_fantasies(np.array([x[0] for x in fb]), np.array([x[1] for x in fb]))
+    f, gr = eng.ei_grad_batch(pts)
+    assert np.allclose(f, g["p_f"], rtol=1e-7, atol=1e-300)
+    assert np.allclose(gr, g["p_g"], rtol=1e-6, atol=1e-9 * np.abs(g["p_g"]).max())
+    # per second
+    comp, vals, ld, hypers, th, pts = (g["s_comp"], g["s_vals"], g["s_log_durs"], g["s_hypers"],
+                                       g["s_time_hypers"], g["s_points"])
+    eng.ei_per_sec_grid(comp, vals, ld, pts, hypers, th)
+    f, gr = eng.ei_grad_batch(pts)
+    assert np.allclose(f, g["s_f"], rtol=1e-7, atol=1e-300)
+    assert np.allclose(gr, g["s_g"], rtol=1e-6, atol=1e-9 * np.abs(g["s_g"]).max())
+
+
+@pytest.mark.parametrize("N,D,H,seed", [(40, 2, 3, 51), (300, 7, 4, 52), (1000, 32, 3, 53)])
+def test_ei_grad_batch_matches_oracle(eng, N, D, H, seed):
+    comp, cand, vals, hypers = synthetic_problem(N, 50, D, H, seed)
+    eng.ei_grid(comp, vals, cand, hypers)
+    rs = np.random.RandomState(seed)
+    pts = np.vstack((cand[:12], comp[np.argmin(vals)] + 1e-3 * rs.randn(4, D), rs.rand(5, D)))   # 21 points: 8 + 8 + 5
+    f, g = eng.ei_grad_batch(pts)
+    for i, x in enumerate(pts):
+        f_ref, g_ref = orc.grad_optimize_ei_over_hypers(x, comp, vals, hypers)
+        assert np.isclose(f[i], f_ref, rtol=1e-7, atol=1e-300)
+        assert np.allclose(g[i], g_ref, rtol=1e-6, atol=1e-9 * max(np.abs(g_ref).max(), 1e-300))
+    # a point's numbers do not depend on the rest of the batch; the single-point entry is the same call
+    for i in (0, 7, 8, 20):
+        fi, gi = eng.ei_grad_batch(pts[i:i + 1])
+        assert fi[0] == f[i] and np.array_equal(gi[0], g[i])
+        f1, g1 = eng.ei_grad(pts[i])
+        assert f1 == f[i] and np.array_equal(g1, g[i])
+    # and it is the gradient of what it says (central differences, reference scaling = 1/2)
+    x = cand[7].copy()
+    for d in range(min(D, 3)):
+        e = np.zeros(D); e[d] = 1e-6
+        fp, _ = eng.ei_grad_batch(np.vstack((x + e, x - e)))
+        assert np.isclose(0.5 * (fp[0] - fp[1]) / 2e-6, g[7][d], rtol=2e-3, atol=1e-9)
+
+
+def test_ei_grad_batch_with_fantasies_matches_oracle(eng):
+    N, P, D, H, S = 300, 4, 6, 3, 100
+    comp, cand, vals, hypers = synthetic_problem(N, 30, D, H, 71)
+    rs = np.random.RandomState(71)
+    pend = rs.rand(P, D)
+    comp_pend = np.concatenate((comp, pend))
+    fb = [orc.fantasize(comp, pend, vals, hypers[h], rs.randn(P, S)) for h in range(H)]
+    fant = np.array([x[0] for x in fb]); bests = np.array([x[1] for x in fb])
+    eng.set_observations(comp_pend, np.concatenate((vals, np.zeros(P))))
+    eng.set_candidates(cand); eng.set_hypers(hypers); eng.factor()
+    eng.set_fantasies(fant, bests)
+    eng.ei_run()                                        # the EI pass the chooser runs first
+    pts = np.vstack((cand[:9], comp[np.argmin(vals)] + 1e-3 * rs.randn(D)))
+    f, g = eng.ei_grad_batch(pts)
+    for i, x in enumerate(pts):
+        f_ref, g_ref = 0.0, np.zeros(D)
+        for h in range(H):
+            e, gr = orc.grad_optimize_ei_fantasies(x, comp_pend, hypers[h], fant[h], bests[h])
+            f_ref += e; g_ref = g_ref + gr
+        assert np.isclose(f[i], f_ref, rtol=1e-7, atol=1e-300)
+        assert np.allclose(g[i], g_ref, rtol=1e-6, atol=1e-9 * max(np.abs(g_ref).max(), 1e-300))
+
+
+def test_more_than_128_fantasies(eng):
+    """pending_samples above 128 (the reference accepts any): numpy's pairwise mean recursion."""
+    N, P, D, H, S = 120, 3, 4, 2, 300
+    comp, cand, vals, hypers = synthetic_problem(N, 500, D, H, 72)
+    rs = np.random.RandomState(72)
+    pend = rs.rand(P, D)
+    comp_pend = np.concatenate((comp, pend))
+    fb = [orc.fantasize(comp, pend, vals, hypers[h], rs.randn(P, S)) for h in range(H)]
+    fant = np.array([x[0] for x in fb]); bests = np.array([x[1] for x in fb])
+    eng.set_observations(comp_pend, np.concatenate((vals, np.zeros(P))))
+    eng.set_candidates(cand); eng.set_hypers(hypers); eng.factor()
+    eng.set_fantasies(fant, bests)
+    eng.ei_run()
+    ref = np.stack([orc.compute_ei_fantasies(comp_pend, cand, hypers[h], fant[h], bests[h]) for h in range(H)], axis=1)
+    got = eng.ei_draws()
+    ok = ref > 1e-280
+    assert np.max(np.abs(got[ok] - ref[ok]) / ref[ok]) <= 1e-6
+    assert eng.best()[0] == orc.choose(ref)
+
+
+def test_ablation_variants_are_not_in_the_shipped_library(eng):
+    with pytest.raises(ValueError):
+        eng.set_option("gemm_waves", 41)
+    with pytest.raises(ValueError):
+        eng.set_option("gemm_waves", 5)
+    comp, cand, vals, hypers = synthetic_problem(300, 2000, 6, 3, 73)
+    try:
+        eng.set_option("gemm_waves", 8)                 # a real variant (8 waves: other summation order in the epilogue)
+        a = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        other = Engine(0)                               # the option is per handle, not per process
+        b = other.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        other.close()
+    finally:
+        eng.set_option("gemm_waves", 0)
+    c = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    assert np.array_equal(b[3], c[3]) and b[0] == c[0]
+    assert a[0] == c[0] and np.allclose(a[3], c[3], rtol=1e-11, atol=1e-300)

@@ -257,30 +257,6 @@ def test_timings_are_reported(eng):
     assert tm["chol_diag"][1] == 256 // 64 and tm["factor_total"][1] == 1
 
 
-# ---- BASELINE.json full sizes: size-independent properties ---------------------------
-def test_c3_full_size_properties(eng):
-    """N_obs=2048, 32-D, 200k candidates, 20 draws (BASELINE config 3)."""
-    N, M, D, H = 2048, 200000, 32, 20
-    comp, cand, vals, hypers = synthetic_problem(N, M, D, H, 3000)
-    idx, val, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
-    # (1) MCMC mean / argmax: device result == numpy on the device's own EI matrix
-    assert np.array_equal(mean, np.mean(draws, axis=1))
-    assert idx == int(np.argmax(mean)) and val == mean[idx]
-    assert np.isfinite(draws).all() and (draws >= 0).all()
-    # (2) a candidate subsample against the CPU oracle (all 20 draws)
-    sub = np.r_[0:10, np.random.RandomState(0).choice(M, 490, replace=False), idx]
-    ref = orc.ei_over_hypers(comp, cand[sub], vals, hypers)
-    assert_ei_close(draws[sub], ref, rtol=1e-6)
-    # (3) per-candidate results do not depend on which other candidates share the launch
-    i2, _, _, d2 = eng.ei_grid(comp, vals, cand[sub], hypers, want_draws=True)
-    assert np.array_equal(d2, draws[sub])
-    assert sub[i2] == idx or mean[sub[i2]] == mean[idx]
-    # (4) a 20 000-candidate subsample (SURVEY 8(d)) for the first and last draw: ~7 s of oracle time
-    big = np.random.RandomState(1).choice(M, 20000, replace=False)
-    for hd in (0, H - 1):
-        assert_ei_close(draws[big, hd], orc.compute_ei(comp, cand[big], vals, hypers[hd]), rtol=1e-6)
-
-
 # ---- the plugin API end to end on the GPU --------------------------------------------
 def test_gpei_chooser_next_on_gpu_matches_reference(golden_dir, tmp_path):
     """examples/braninpy through GPEIChooser.next: same seeded hypers, same job
@@ -439,31 +415,6 @@ def test_choosers_with_pending_on_gpu_match_reference(golden_dir, tmp_path):
         assert job == int(g["p_index"])
 
 
-# ---- local refinement objective ("next" row 3): EI and gradient at a point on the GPU ------------
-@pytest.mark.parametrize("N,D,H,seed", [(40, 2, 3, 51), (300, 7, 4, 52), (1000, 32, 3, 53)])
-def test_ei_grad_matches_host_model(eng, N, D, H, seed):
-    from spearmint_amd import hostgp
-    comp, cand, vals, hypers = synthetic_problem(N, 50, D, H, seed)
-    eng.ei_grid(comp, vals, cand, hypers)            # leaves observations, draws and factors resident
-    models = [hostgp.PointModel(comp, vals, (h[0], h[1], h[2], h[3:])) for h in hypers]
-    rs = np.random.RandomState(seed)
-    for x in [cand[3], comp[5] + 1e-3 * rs.randn(D), rs.rand(D)]:
-        f_ref, g_ref = 0.0, np.zeros(D)
-        for m in models:
-            e, g = m.neg_ei_and_grad(x)
-            f_ref += e; g_ref = g_ref + g
-        f, g = eng.ei_grad(x)
-        assert np.isclose(f, f_ref, rtol=1e-7, atol=1e-300)
-        assert np.allclose(g, g_ref, rtol=1e-6, atol=1e-9 * np.abs(g_ref).max())
-    # and it is the gradient of what it says (central differences, reference scaling = 1/2)
-    x = cand[7].copy()
-    f0, g = eng.ei_grad(x)
-    for d in range(min(D, 3)):
-        e = np.zeros(D); e[d] = 1e-6
-        num = (eng.ei_grad(x + e)[0] - eng.ei_grad(x - e)[0]) / 2e-6
-        assert np.isclose(0.5 * num, g[d], rtol=2e-3, atol=1e-9)
-
-
 def test_opt_chooser_with_gpu_refinement_matches_reference(golden_dir, tmp_path):
     from spearmint_amd.chooser import GPEIOptChooser
     g = _g(golden_dir, "chooser_next.npz")
@@ -473,64 +424,6 @@ def test_opt_chooser_with_gpu_refinement_matches_reference(golden_dir, tmp_path)
     job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
     assert isinstance(job, tuple) and job[0] == int(g["opt_index"])
     assert np.allclose(job[1], g["opt_point"], atol=1e-5)
-
-
-def test_c5_shard_per_second_properties(eng):
-    """BASELINE config 5 per-GPU shard: dual GP (objective + log-duration), 16-D,
-    N_obs=1024, 62 500 candidates, 20 draws."""
-    N, M, D, H = 1024, 62500, 16, 20
-    comp, cand, vals, hypers, log_durs, th = synthetic_problem(N, M, D, H, 5000, per_sec=True)
-    idx, val, mean, draws = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
-    assert np.array_equal(mean, np.mean(draws, axis=1)) and idx == int(np.argmax(mean))
-    sub = np.r_[0:10, np.random.RandomState(1).choice(M, 290, replace=False), idx]
-    ref = orc.ei_per_s_over_hypers(comp, cand[sub], vals, log_durs, hypers, th)
-    assert_ei_close(draws[sub], ref, rtol=1e-6)
-    # EI/s = EI / predicted duration: dividing out the plain EI recovers exp(time mean) > 0
-    plain = eng.ei_grid(comp, vals, cand[sub], hypers, want_draws=True)[3]
-    ok = plain > 1e-200
-    assert np.all(plain[ok] / draws[sub][ok] > 0)
-
-
-def test_c4_shard_properties_and_two_shards(eng):
-    """BASELINE config 4: the candidate grid sharded contiguously; two of the eight
-    125k-candidate shards scored one after the other and combined by the all-reduce rule."""
-    N, D, H, Ms = 2048, 32, 20, 125000
-    comp, _, vals, hypers = synthetic_problem(N, 16, D, H, 4000, near=0)
-    eng.set_observations(comp, vals); eng.set_hypers(hypers); eng.factor()
-    recs, keep = [], []
-    for r in range(2):
-        shard = np.random.RandomState(4000 + r).rand(Ms, D)
-        eng.set_candidates(shard, index_base=r * Ms)
-        eng.ei_run()
-        i, v = eng.best()
-        m = eng.ei_mean()
-        assert r * Ms <= i < (r + 1) * Ms and v == m[i - r * Ms] == m.max()
-        recs.append([v, i]); keep.append((shard, m))
-    gi, gv = sd.pick_best(recs)
-    allm = np.concatenate([k[1] for k in keep])
-    assert gi == int(np.argmax(allm)) and gv == allm.max()
-    # oracle spot check on the winning shard
-    shard, m = keep[gi // Ms]
-    sub = np.r_[gi % Ms, 0:63]
-    ref = orc.ei_over_hypers(comp, shard[sub], vals, hypers)
-    assert np.allclose(m[sub], np.mean(ref, axis=1), rtol=1e-6, atol=1e-300)
-
-
-def test_multi_engine_matches_single(eng):
-    """Several engines in one process (here: two handles on the one GPU of the test box):
-    contiguous candidate shards + the argmax rule == the single-engine answer, bitwise."""
-    from spearmint_amd.engine import MultiEngine
-    comp, cand, vals, hypers = synthetic_problem(200, 3001, 5, 4, 61)
-    one = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
-    me = MultiEngine([0, 0, 0])
-    try:
-        many = me.ei_grid(comp, vals, cand, hypers, want_draws=True)
-        assert many[0] == one[0] and many[1] == one[1]
-        assert np.array_equal(many[2], one[2]) and np.array_equal(many[3], one[3])
-        lp = me.gp_logprob()
-        assert lp.shape == (4,)
-    finally:
-        me.close()
 
 
 def test_chooser_with_ndev(golden_dir, tmp_path):
@@ -557,19 +450,3 @@ def test_two_stream_mode_is_bit_identical(eng):
         eng.set_option("kstar_budget_bytes", 0)
     assert a[0] == b[0] and np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
     assert ap[0] == bp[0] and np.array_equal(ap[3], bp[3])
-
-
-def test_ei_per_second_grad_matches_host_model(eng):
-    from spearmint_amd import hostgp
-    comp, cand, vals, hypers, log_durs, th = synthetic_problem(200, 60, 5, 3, 81, per_sec=True)
-    eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th)
-    models = [hostgp.PerSecPointModel(comp, vals, log_durs, (h[0], h[1], h[2], h[3:]), (t[0], t[1], t[2], t[3:]))
-              for h, t in zip(hypers, th)]
-    for x in [cand[2], comp[9] + 1e-3, np.random.RandomState(3).rand(5)]:
-        f_ref, g_ref = 0.0, np.zeros(5)
-        for m in models:
-            e, g = m.neg_ei_and_grad(x)
-            f_ref += e; g_ref = g_ref + g
-        f, g = eng.ei_grad(x)
-        assert np.isclose(f, f_ref, rtol=1e-7, atol=1e-300)
-        assert np.allclose(g, g_ref, rtol=1e-6, atol=1e-9 * np.abs(g_ref).max())
