@@ -11,7 +11,7 @@ comp, cand, vals, _ = synthetic_problem(N, M, D, 1, 9)
 grid = np.vstack((comp, cand)); values = np.concatenate((vals, np.full(M, np.nan)))
 durations = np.ones(N + M)
 complete = np.arange(N); candidates = np.arange(N, N + M); pending = np.array([], dtype=int)
-ch = GPEIOptChooser.init(tempfile.mkdtemp(), "burnin=2,use_multiprocessing=0," + (sys.argv[5] if len(sys.argv) > 5 else "mcmc_iters=4,grid_subset=4") + (("," + sys.argv[4]) if len(sys.argv) > 4 else ""))
+ch = GPEIOptChooser.init(tempfile.mkdtemp(), "burnin=2,use_multiprocessing=0," + (sys.argv[5] if len(sys.argv) > 5 else "mcmc_iters=4,grid_subset=4") + (("," + sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] else ""))
 npr.seed(3)
 ch.engine().set_observations(comp, vals)   # GPU / library warm-up outside the profile
 pr = cProfile.Profile()

@@ -79,6 +79,58 @@ __device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B
 }
 
 // ---------------------------------------------------------------------------
+// Cholesky factor AND inverse of one symmetric 16x16 block, by one wavefront, on the matrix pipe.
+// The block sits in the MFMA accumulator layout (reg r of lane (c, q) = element [q + 4r][c]); so
+// does X, which starts as the identity.  Pivot j (row j = q + 4r with q = j & 3, r = j >> 2):
+//   d = C[j][j]  (v_readlane),  rinv = d^-1/2  (v_rsq_f64 + one third-order step, ~1 ulp);
+//   the lanes of group q = j & 3 hold row j of C -- which, C being symmetric, is column j -- in
+//   reg j >> 2, exactly where the A / B operands of k-slot j & 3 are read from, so
+//       C <- C - l l^T             l = C[:, j] rinv      (column j of L)
+//       X <- X - l_{>j} (x_j rinv) x_j = row j of X      (row operations that turn I into L^-1)
+//   are ONE v_mfma_f64_16x16x4 each (three k-slots zero) with operands straight out of the
+//   accumulator registers: no cross-lane traffic except the one readlane of the pivot.
+// The dependent chain per pivot is readlane -> rsq -> 5 fma -> 2 mul -> MFMA, against ~1100
+// dependent VALU / readlane instructions for the register-row formulation it replaces (65 % of
+// k_chol_diag's 30 us: 8.5k cycles per 16x16 block).
+// Out: U[r] = (L^T)[q + 4r][c] (upper, zeros below the diagonal), X = L^-1 (lower).
+// Rows and columns < j of C are dead after their pivot (they collect garbage; nothing reads them).
+__device__ __forceinline__ void factor16_mfma(d4& C, d4& X, d4& U, int lane, int& bad, int pivot_base)
+{
+    const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        X[r] = (q + 4 * r == c) ? 1.0 : 0.0;
+        U[r] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int kq = j & 3, rj = j >> 2;
+        double d = readlane_f64(C[rj], j + 16 * kq);
+        if (!(d > 0.0)) {  // also catches NaN, like LAPACK dpotrf's (ajj <= 0 || isnan)
+            if (!bad) bad = pivot_base + j + 1;
+            d = 1.0;
+        }
+        const double y0 = __builtin_amdgcn_rsq(d);
+        const double e0 = fma(-d * y0, y0, 1.0);
+        const double rinv = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+        const bool grp = (q == kq);
+        const double lcol = C[rj] * rinv;
+        const double b = grp ? lcol : 0.0;
+        const double xs = X[rj] * rinv;
+        const double bX = grp ? xs : 0.0;
+        const double aX = (grp && c > j) ? -lcol : 0.0;
+        C = MFMA_F64(-b, b, C);
+        X = MFMA_F64(aX, bX, X);
+        X[rj] = grp ? xs : X[rj];
+        // the diagonal entry sqrt(d) to ~0.5 ulp (off the critical path)
+        double sd = d * rinv;
+        sd = fma(fma(-sd, sd, d), 0.5 * rinv, sd);
+        const double keep = (c == j) ? sd : ((c > j) ? lcol : 0.0);
+        U[rj] = grp ? keep : U[rj];
+    }
+}
+
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, double* __restrict__ Dinv,
                                                    int* __restrict__ info, int Np, int k, int updated)
 {
@@ -116,58 +168,25 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
     __syncthreads();
 
     // ---- blocked Cholesky of the 64x64 block, 16x16 sub-blocks ----------------------------
-    // per sub-block column b: (a) one wavefront factors the 16x16 diagonal sub-block with the
-    // row of lane i in registers (pivot column broadcast lane-to-lane by v_readlane) and
-    // inverts it; (b) the sub-panel below is multiplied by that inverse (MFMA); (c) the
-    // trailing sub-blocks get their rank-16 update (MFMA).
+    // per sub-block column b: (a) one wavefront factors and inverts the 16x16 diagonal sub-block
+    // on the matrix pipe (factor16_mfma: one rank-1 MFMA per pivot for the factor, one for the
+    // inverse); (b) the sub-panel below is multiplied by that inverse (MFMA); (c) the trailing
+    // sub-blocks get their rank-16 update (MFMA).
     int bad = 0;
     for (int b = 0; b < 4; ++b) {
         const int b0 = 16 * b;
         double* Tb = T16 + b * 16 * 18;
         if (wave == 0) {
-            const int i = li;   // the four 16-lane groups hold identical copies
-            double a[16], rinvs[16];
+            d4 C, X, U;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = S[(b0 + i) * LDP + b0 + c];
+            for (int r = 0; r < 4; ++r) C[r] = S[(b0 + g + 4 * r) * LDP + b0 + li];
+            factor16_mfma(C, X, U, lane, bad, (int)kb0 + b0);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double d = readlane_f64(a[j], j);
-                if (!(d > 0.0)) {  // also catches NaN, like LAPACK dpotrf's (ajj <= 0 || isnan)
-                    if (!bad) bad = (int)kb0 + b0 + j + 1;
-                    d = 1.0;
-                }
-                // 1/sqrt(d) and sqrt(d) to ~1 ulp from v_rsq_f64 + Newton steps: this pair sits on the
-                // critical path of every pivot, and the library sqrt + division cost ~50 dependent
-                // instructions where these take 9
-                const double y0 = __builtin_amdgcn_rsq(d);
-                const double e0 = fma(-d * y0, y0, 1.0);
-                const double rinv = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
-                double sd = d * rinv;
-                sd = fma(fma(-sd, sd, d), 0.5 * rinv, sd);
-                rinvs[j] = rinv;
-                double lij = 0.0;
-                if (i > j) lij = a[j] * rinv;
-                else if (i == j) lij = sd;
-                a[j] = lij;
-#pragma unroll
-                for (int kc = j + 1; kc < 16; ++kc) a[kc] -= lij * readlane_f64(lij, kc);
-            }
-            // inverse of the 16x16 factor: lane c builds column c by forward substitution
-            double x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                double t = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-                for (int p = 0; p < r; ++p) t -= readlane_f64(a[p], r) * x[p];
-                x[r] = (r >= i) ? t * rinvs[r] : 0.0;
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    S[(b0 + i) * LDP + b0 + c] = (c <= i) ? a[c] : 0.0;
-                    Tb[c * 18 + i] = x[c];                      // Linv16[r = c][col = i]
-                    XT[(b0 + i) * LDP + b0 + c] = x[c];         // XT[col][row] = X[row][col]
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int row = g + 4 * r;                      // U[row][li] = L[li][row]
+                S[(b0 + li) * LDP + b0 + row] = U[r];           // lower triangle incl. diagonal, zeros above
+                Tb[row * 18 + li] = X[r];                       // Linv16[row][col = li]
+                XT[(b0 + li) * LDP + b0 + row] = X[r];          // XT[col][row] = X[row][col]
             }
         }
         __syncthreads();
