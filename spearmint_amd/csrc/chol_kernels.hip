@@ -131,47 +131,44 @@ __device__ __forceinline__ void factor16_mfma(d4& C, d4& X, d4& U, int lane, int
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, double* __restrict__ Dinv,
-                                                   int* __restrict__ info, int Np, int k, int updated)
+// Factor the 64x64 block held (full, symmetric) in S and invert the factor; 256 threads.
+//   S   [64][LDP]  in: the updated diagonal block; out: L_kk in the lower triangle
+//   XT  [64][LDP]  out: (L_kk^-1)^T
+//   T16 [4][16][18] scratch: inverses of the 16x16 diagonal sub-blocks
+// then write L_kk (upper part zero) to Lkk (row stride ldl) and L_kk^-1 to Dk ([64][64]).
+// Blocked with 16x16 sub-blocks.  Per sub-block column b: (a) one wavefront factors and inverts the
+// diagonal sub-block on the matrix pipe (factor16_mfma); meanwhile the other three build the
+// off-diagonal blocks of row b-1 of the inverse, which only need what round b-1 finished; (b) the
+// sub-panel below is multiplied by the sub-block's inverse (MFMA); (c) the trailing sub-blocks get
+// their rank-16 update (MFMA).  Inverse by block forward substitution:
+//   X_jj = Linv16_j ;  X_ij = -Linv16_i * sum_{p=j}^{i-1} L_ip X_pj          (i > j)
+// XT holds X transposed so that X_pj is read in the MFMA B-operand pattern; the accumulator of the
+// first product is itself in B-operand layout for the second.
+__device__ __forceinline__ void inv_block_row(const double* S, double* XT, const double* T16, int i, int j,
+                                              int g, int li)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* P = smem;                  // [2][64][LDP] staging tiles of the row panel (double-buffered)
-    double* S = P + 2 * NB * LDP;      // [64][LDP] the diagonal block, factored in place
-    double* XT = S + NB * LDP;         // [64][LDP] (L_kk^-1)^T
-    double* T16 = XT + NB * LDP;       // [4][16][18] inverses of the 16x16 diagonal sub-blocks
+    d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int pb = j; pb < i; ++pb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const double av = S[(16 * i + li) * LDP + 16 * pb + 4 * ks + g];
+            const double bv = XT[(16 * j + li) * LDP + 16 * pb + 4 * ks + g];
+            t4 = MFMA_F64(av, bv, t4);
+        }
+    }
+    d4 o4 = (d4){0.0, 0.0, 0.0, 0.0};
+    const double* Ti = T16 + i * 16 * 18;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o4 = MFMA_F64(-Ti[li * 18 + 4 * ks + g], t4[ks], o4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
+}
+
+__device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, int* info_h, int pivot_base,
+                                           double* __restrict__ Lkk, size_t ldl, double* __restrict__ Dk)
+{
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.x;
-    const int nblk = Np / NB;
-    double* Lh = Lm + (size_t)h * Np * Np;
-    const size_t kb0 = (size_t)k * NB;
-
-    // S = K_kk - sum_p L_kp L_kp^T
-    d4 acc[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[nt][r] = Lh[(kb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
-    // steps p < k-1 were already applied in place by the previous panel launch (k_chol_panel,
-    // diag_pre); only p = k-1, whose tile that launch produced, is left.  In right-looking mode
-    // (k_chol_update) the block arrives fully updated.
-    if (k > 0 && !updated) {
-        tile_to_lds(Lh + kb0 * Np + (size_t)(k - 1) * NB, Np, P);
-        __syncthreads();
-        mma_tile_64(P, P, acc, wave, g, li, true);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
-    __syncthreads();
-
-    // ---- blocked Cholesky of the 64x64 block, 16x16 sub-blocks ----------------------------
-    // per sub-block column b: (a) one wavefront factors and inverts the 16x16 diagonal sub-block
-    // on the matrix pipe (factor16_mfma: one rank-1 MFMA per pivot for the factor, one for the
-    // inverse); (b) the sub-panel below is multiplied by that inverse (MFMA); (c) the trailing
-    // sub-blocks get their rank-16 update (MFMA).
     int bad = 0;
     for (int b = 0; b < 4; ++b) {
         const int b0 = 16 * b;
@@ -180,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
             d4 C, X, U;
 #pragma unroll
             for (int r = 0; r < 4; ++r) C[r] = S[(b0 + g + 4 * r) * LDP + b0 + li];
-            factor16_mfma(C, X, U, lane, bad, (int)kb0 + b0);
+            factor16_mfma(C, X, U, lane, bad, pivot_base + b0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = g + 4 * r;                      // U[row][li] = L[li][row]
@@ -188,6 +185,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
                 Tb[row * 18 + li] = X[r];                       // Linv16[row][col = li]
                 XT[(b0 + li) * LDP + b0 + row] = X[r];          // XT[col][row] = X[row][col]
             }
+        } else if (wave < b) {
+            inv_block_row(S, XT, T16, b - 1, wave - 1, g, li);   // row b-1 of the inverse, block column wave-1
         }
         __syncthreads();
         // (b) sub-panel: rows of tile ti = b+1+wave, P <- P Linv16^T
@@ -225,49 +224,68 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
                     for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li] = c4[r];
                 }
         }
-        __syncthreads();
+        if (b < 3) __syncthreads();   // round 3 has no sub-panel / trailing work: nothing was written
     }
     if (wave == 0 && lane == 0 && bad) {
-        if (info[h] == 0) info[h] = bad;
+        if (*info_h == 0) *info_h = bad;
     }
-
-    // ---- X = L_kk^-1 by block forward substitution, wave j owns sub-block column j -----------
-    //   X_jj = Linv16_j ;  X_ij = -Linv16_i * sum_{p=j}^{i-1} L_ip X_pj          (i > j)
-    // XT holds X transposed so that X_pj is read in the MFMA B-operand pattern; the
-    // accumulator of the first product is itself in B-operand layout for the second.
-    {
-        const int j = wave;
-        for (int i = j + 1; i < 4; ++i) {
-            d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};
-            for (int pb = j; pb < i; ++pb) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const double av = S[(16 * i + li) * LDP + 16 * pb + 4 * ks + g];
-                    const double bv = XT[(16 * j + li) * LDP + 16 * pb + 4 * ks + g];
-                    t4 = MFMA_F64(av, bv, t4);
-                }
-            }
-            d4 o4 = (d4){0.0, 0.0, 0.0, 0.0};
-            const double* Ti = T16 + i * 16 * 18;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) o4 = MFMA_F64(-Ti[li * 18 + 4 * ks + g], t4[ks], o4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
-        }
-    }
+    if (wave < 3) inv_block_row(S, XT, T16, 3, wave, g, li);   // last row of the inverse
     __syncthreads();
-    // write L_kk (upper part zero) and its inverse
-    double* Dk = Dinv + ((size_t)h * nblk + k) * NB * NB;
-    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
-        const int row = idx >> 6, col = idx & 63;
-        Lh[(kb0 + row) * Np + kb0 + col] = (col <= row) ? S[row * LDP + col] : 0.0;
-        Dk[idx] = (col <= row) ? XT[col * LDP + row] : 0.0;
+    // write L_kk (upper part zero) and its inverse, 16 bytes per lane
+    for (int idx = threadIdx.x; idx < NB * NB / 2; idx += 256) {
+        const int row = idx >> 5, col = (idx & 31) * 2;
+        d2 lv, xv;
+        lv[0] = (col <= row) ? S[row * LDP + col] : 0.0;
+        lv[1] = (col + 1 <= row) ? S[row * LDP + col + 1] : 0.0;
+        xv[0] = (col <= row) ? XT[col * LDP + row] : 0.0;
+        xv[1] = (col + 1 <= row) ? XT[(col + 1) * LDP + row] : 0.0;
+        *reinterpret_cast<d2*>(Lkk + (size_t)row * ldl + col) = lv;
+        *reinterpret_cast<d2*>(Dk + row * NB + col) = xv;
     }
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, double* __restrict__ Dinv,
+                                                   int* __restrict__ info, int Np, int k, int updated)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* P = smem;                  // [64][LDP] staging tile of the row panel
+    double* S = P + NB * LDP;          // [64][LDP] the diagonal block, factored in place
+    double* XT = S + NB * LDP;         // [64][LDP] (L_kk^-1)^T
+    double* T16 = XT + NB * LDP;       // [4][16][18] inverses of the 16x16 diagonal sub-blocks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x;
+    const int nblk = Np / NB;
+    double* Lh = Lm + (size_t)h * Np * Np;
+    const size_t kb0 = (size_t)k * NB;
+
+    // S = K_kk - sum_p L_kp L_kp^T
+    d4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[nt][r] = Lh[(kb0 + 16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
+    // steps p < k-1 were already applied in place by the previous panel launch (k_chol_panel,
+    // diag_pre); only p = k-1, whose tile that launch produced, is left.
+    if (k > 0 && !updated) {
+        tile_to_lds(Lh + kb0 * Np + (size_t)(k - 1) * NB, Np, P);
+        __syncthreads();
+        mma_tile_64(P, P, acc, wave, g, li, true);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
+    __syncthreads();
+    diag_block(S, XT, T16, info + h, (int)kb0, Lh + kb0 * Np + kb0, (size_t)Np,
+               Dinv + ((size_t)h * nblk + k) * NB * NB);
 }
 
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh, int updated)
 {
-    const size_t lds = (size_t)(4 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 144 KB > the 64 KB default
+    const size_t lds = (size_t)(3 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 110 KB > the 64 KB default
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k, updated);
@@ -371,51 +389,78 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 }
 
 // ---------------------------------------------------------------------------
-// k_chol_update: right-looking trailing update after block column k,
-//   A_ij -= L_ik L_jk^T   for every lower tile k < j <= i   (and the right-hand-side rows),
-// one 64-deep MFMA step per tile, in place.  Used by the log-likelihood path, where a handful of
-// draws cannot fill the chip with the left-looking panel (a tile's k steps run sequentially in
-// one workgroup: 1.8 ms of critical path at N=2048); here every launch is one step deep.  The
-// steps reach each tile in the same order p = 0, 1, ... as in the left-looking kernel, so the
-// factor is bit-identical.
-__global__ __launch_bounds__(256, 2) void k_chol_update(double* __restrict__ Lm, double* __restrict__ rhs,
-                                                     int Np, int k)
+// k_lean_step: one step of the right-looking factorisation the log-likelihood path uses (a handful of
+// draws cannot fill the chip with the left-looking panel, whose k steps per tile run sequentially
+// in one workgroup).  Launch k applies update step k-1 to every remaining lower tile,
+//   A_ij -= L_i,k-1 L_j,k-1^T      for k <= j <= i   (and the right-hand-side rows),
+// one 64-deep MFMA step per tile, in place -- and the workgroup that owns the diagonal tile (k, k),
+// which is thereby complete, goes straight on to factor and invert it (diag_block), so that the
+// serial part of the factorisation (the 64x64 diagonal blocks, ~20 us each) runs beside the bulk of
+// the update instead of in a launch of its own: two launches per block column (this one and the
+// triangular solve of the panel, k_chol_panel) instead of three, and the update of step k-1 is
+// hidden behind the diagonal block of step k or the other way round.  The steps reach each tile in
+// the order p = 0, 1, ... as in the left-looking kernel, so the factor is bit-identical.
+// Grid (rows, columns, draws) over the trailing tiles; k = 0: only the diagonal workgroup.
+__global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lm, double* __restrict__ Dinv,
+                                                   int* __restrict__ info, double* __restrict__ rhs, int Np,
+                                                   int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* A = smem;              // [64][LDP]  L_ik (or the right-hand-side rows' block k)
-    double* B = smem + NB * LDP;   // [64][LDP]  L_jk
+    double* A = smem;              // [64][LDP]  L_i,k-1 (or the right-hand-side rows' block k-1); then S
+    double* B = smem + NB * LDP;   // [64][LDP]  L_j,k-1; then XT
+    double* T16 = B + NB * LDP;    // [4][16][18]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int h = blockIdx.z;
+    const int nblk = Np / NB;
     const bool is_rhs = rhs && blockIdx.x == gridDim.x - 1;
-    const int i = k + 1 + blockIdx.x, j = k + 1 + blockIdx.y;
+    const int i = k + blockIdx.x, j = k + blockIdx.y;
     if (!is_rhs && j > i) return;
     double* Lh = Lm + (size_t)h * Np * Np;
     double* Ar = is_rhs ? rhs + (size_t)h * NB * Np : Lh + (size_t)i * NB * Np;
-    const size_t kb0 = (size_t)k * NB, jb0 = (size_t)j * NB;
+    const size_t jb0 = (size_t)j * NB;
     d4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[nt][r] = Ar[(size_t)(16 * wave + g + 4 * r) * Np + jb0 + 16 * nt + li];
-    tile_to_lds(Ar + kb0, Np, A);
-    tile_to_lds(Lh + jb0 * Np + kb0, Np, B);
-    __syncthreads();
-    mma_tile_64(A, B, acc, wave, g, li, true);
+    if (k > 0) {
+        const size_t pb0 = (size_t)(k - 1) * NB;
+        tile_to_lds(Ar + pb0, Np, A);
+        tile_to_lds(Lh + jb0 * Np + pb0, Np, B);
+        __syncthreads();
+        mma_tile_64(A, B, acc, wave, g, li, true);
+    }
+    if (!is_rhs && i == k && j == k) {
+        // the serial part of the factorisation: let its MFMAs and VALU win the arbitration against
+        // the update workgroup that shares this CU
+        __builtin_amdgcn_s_setprio(3);
+        __syncthreads();           // every wave is done reading A / B
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
+        __syncthreads();
+        diag_block(A, B, T16, info + h, k * NB, Lh + jb0 * Np + jb0, (size_t)Np,
+                   Dinv + ((size_t)h * nblk + k) * NB * NB);
+        return;
+    }
+    if (k == 0) return;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Ar[(size_t)(16 * wave + g + 4 * r) * Np + jb0 + 16 * nt + li] = acc[nt][r];
 }
 
-void launch_chol_update(hipStream_t s, double* L, double* rhs, int Np, int k, int nh)
+void launch_lean_step(hipStream_t s, double* L, double* Dinv, int* info, double* rhs, int Np, int k, int nh)
 {
-    const int n = Np / NB - k - 1;
+    const int n = Np / NB - k;
     if (n <= 0) return;
-    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);   // 67.6 KB
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_update),
+    const size_t lds = (size_t)(2 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 72 KB: two workgroups per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_chol_update, dim3(n + (rhs ? 1 : 0), n, nh), dim3(256), lds, s, L, rhs, Np, k);
+    const dim3 grid = (k == 0) ? dim3(1, 1, nh) : dim3(n + (rhs ? 1 : 0), n, nh);
+    hipLaunchKernelGGL(k_lean_step, grid, dim3(256), lds, s, L, Dinv, info, (k == 0) ? nullptr : rhs, Np, k);
 }
 
 // ---------------------------------------------------------------------------

@@ -42,7 +42,7 @@ void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const 
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh, int updated = 0);
 void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs = nullptr,
                        int right_looking = 0);
-void launch_chol_update(hipStream_t s, double* L, double* rhs, int Np, int k, int nh);
+void launch_lean_step(hipStream_t s, double* L, double* Dinv, int* info, double* rhs, int Np, int k, int nh);
 void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh);
 void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
                   double* gamma, int N, int Np, int nh);

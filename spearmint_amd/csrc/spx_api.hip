@@ -306,12 +306,13 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     }
     // Blocked left-looking Cholesky for the EI path (many draws: every panel launch fills the chip).
     // The log-likelihood path (a handful of draws) runs the same tiles right-looking: one-step-deep
-    // launches instead of k sequential steps per tile; same accumulation order, same bits.
+    // launches instead of k sequential steps per tile, the diagonal block factored inside the update
+    // launch (k_lean_step); same accumulation order, same bits.
     const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
     for (int k = 0; k < nblk; ++k) {
-        TIMED(ST_CHOL_DIAG, launch_chol_diag(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, Np, k, nh, rl));
+        if (rl) TIMED(ST_CHOL_DIAG, launch_lean_step(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, Np, k, nh));
+        else TIMED(ST_CHOL_DIAG, launch_chol_diag(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, Np, k, nh, 0));
         if (k + 1 < nblk || rhs) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh, rhs, rl));
-        if (rl && k + 1 < nblk) TIMED(ST_CHOL_PANEL, launch_chol_update(s, h->Lm.d(), rhs, Np, k, nh));
     }
     if (!lean) {
         TIMED(ST_TRINV, launch_trinv(s, h->Lm.d(), h->Dinv.d(), h->WT.d(), Np, nh));
