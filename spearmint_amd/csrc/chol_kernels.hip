@@ -401,6 +401,7 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 // hidden behind the diagonal block of step k or the other way round.  The steps reach each tile in
 // the order p = 0, 1, ... as in the left-looking kernel, so the factor is bit-identical.
 // Grid (rows, columns, draws) over the trailing tiles; k = 0: only the diagonal workgroup.
+#define LEAN_CH 4   // trailing tiles of one block row handled by one workgroup (the row operand stays in LDS)
 __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lm, double* __restrict__ Dinv,
                                                    int* __restrict__ info, double* __restrict__ rhs, int Np,
                                                    int k)
@@ -414,42 +415,61 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lm, d
     const int h = blockIdx.z;
     const int nblk = Np / NB;
     const bool is_rhs = rhs && blockIdx.x == gridDim.x - 1;
-    const int i = k + blockIdx.x, j = k + blockIdx.y;
-    if (!is_rhs && j > i) return;
+    const int i = k + blockIdx.x;
+    // this workgroup's tiles: block row i (or the right-hand-side rows), block columns j0 .. j1 - 1
+    const int j0 = k + blockIdx.y * LEAN_CH;
+    const int j1 = min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
+    if (j0 >= j1) return;
     double* Lh = Lm + (size_t)h * Np * Np;
     double* Ar = is_rhs ? rhs + (size_t)h * NB * Np : Lh + (size_t)i * NB * Np;
-    const size_t jb0 = (size_t)j * NB;
-    d4 acc[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[nt][r] = Ar[(size_t)(16 * wave + g + 4 * r) * Np + jb0 + 16 * nt + li];
-    if (k > 0) {
-        const size_t pb0 = (size_t)(k - 1) * NB;
-        tile_to_lds(Ar + pb0, Np, A);
-        tile_to_lds(Lh + jb0 * Np + pb0, Np, B);
-        __syncthreads();
-        mma_tile_64(A, B, acc, wave, g, li, true);
-    }
-    if (!is_rhs && i == k && j == k) {
-        // the serial part of the factorisation: let its MFMAs and VALU win the arbitration against
-        // the update workgroup that shares this CU
-        __builtin_amdgcn_s_setprio(3);
-        __syncthreads();           // every wave is done reading A / B
+    const size_t pb0 = (size_t)(k > 0 ? k - 1 : 0) * NB;
+    auto load_acc = [&](int j, d4 (&acc)[4]) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) A[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
-        __syncthreads();
-        diag_block(A, B, T16, info + h, k * NB, Lh + jb0 * Np + jb0, (size_t)Np,
-                   Dinv + ((size_t)h * nblk + k) * NB * NB);
-        return;
+            for (int r = 0; r < 4; ++r)
+                acc[nt][r] = Ar[(size_t)(16 * wave + g + 4 * r) * Np + (size_t)j * NB + 16 * nt + li];
+    };
+    d4 acc[4], accn[4];
+    TileRegs tb;
+    load_acc(j0, accn);
+    if (k > 0) {
+        tile_load(Lh + (size_t)j0 * NB * Np + pb0, Np, tb);
+        tile_to_lds(Ar + pb0, Np, A);      // the row operand, once
     }
-    if (k == 0) return;
+    for (int j = j0; j < j1; ++j) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = accn[nt];
+        if (k > 0) {
+            tile_store(tb, B);
+            __syncthreads();
+            if (j + 1 < j1) {              // the next tile's operand and accumulator fly while this one computes
+                tile_load(Lh + (size_t)(j + 1) * NB * Np + pb0, Np, tb);
+                load_acc(j + 1, accn);
+            }
+            mma_tile_64(A, B, acc, wave, g, li, true);
+        }
+        if (!is_rhs && i == k && j == k) {
+            // the serial part of the factorisation (this is the only tile of this workgroup)
+            __builtin_amdgcn_s_setprio(3);
+            __syncthreads();           // every wave is done reading A / B
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ar[(size_t)(16 * wave + g + 4 * r) * Np + jb0 + 16 * nt + li] = acc[nt][r];
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
+            __syncthreads();
+            diag_block(A, B, T16, info + h, k * NB, Lh + (size_t)j * NB * Np + (size_t)j * NB, (size_t)Np,
+                       Dinv + ((size_t)h * nblk + k) * NB * NB);
+            return;
+        }
+        if (k == 0) return;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ar[(size_t)(16 * wave + g + 4 * r) * Np + (size_t)j * NB + 16 * nt + li] = acc[nt][r];
+        __syncthreads();               // B is rewritten for the next tile
+    }
 }
 
 void launch_lean_step(hipStream_t s, double* L, double* Dinv, int* info, double* rhs, int Np, int k, int nh)
@@ -459,7 +479,7 @@ void launch_lean_step(hipStream_t s, double* L, double* Dinv, int* info, double*
     const size_t lds = (size_t)(2 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 72 KB: two workgroups per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const dim3 grid = (k == 0) ? dim3(1, 1, nh) : dim3(n + (rhs ? 1 : 0), n, nh);
+    const dim3 grid = (k == 0) ? dim3(1, 1, nh) : dim3(n + (rhs ? 1 : 0), (n + LEAN_CH - 1) / LEAN_CH, nh);
     hipLaunchKernelGGL(k_lean_step, grid, dim3(256), lds, s, L, Dinv, info, (k == 0) ? nullptr : rhs, Np, k);
 }
 
