@@ -24,6 +24,7 @@ Fixtures (all float64, ref = the reference's own functions):
                    (seeded; burnin + MCMC + refinement), the point they propose.
   chooser_next_pending.npz  the same with three pending jobs (fantasy branch).
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
+  chooser_next_ml2.npz  GPEIChooser.next with mcmc_iters=0 (ML-II hypers, gp.py:181-292).
   ei_grad.npz      the refinement objective: GPEIOptChooser.grad_optimize_ei_over_hypers
                    without and with pending jobs, GPEIperSecChooser.grad_optimize_ei_over_hypers
                    (value + gradient at several points each).
@@ -315,6 +316,19 @@ def gen_slice(mods, tmp):
                         lp_at_ones=lp_ls(np.ones(3)))
 
 
+def gen_ml2(mods, tmp):
+    """mcmc_iters=0: GPEIChooser.next with the ML-II hyper optimisation of gp.GP.optimize_hypers
+    (gp.py:181-292).  (The same setting makes the reference's GPEIOptChooser and GPEIperSecChooser
+    raise -- ValueError / UnboundLocalError -- so there is nothing to record for them.)"""
+    grid, values, durations, cand, pend, comp = _branin_inputs(mods, 12, 400)
+    ch = mods["GPEIChooser"].GPEIChooser(tempfile.mkdtemp(prefix="spx_golden_ml2_"), mcmc_iters=0)
+    npr.seed(5)
+    job = ch.next(grid, values, durations, cand, pend, comp)
+    np.savez_compressed(os.path.join(OUT, "chooser_next_ml2.npz"), grid=grid, values=values, durations=durations,
+                        candidates=cand, pending=pend, complete=comp, job=int(job),
+                        hyper=np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)))
+
+
 def gen_ei_grad(mods, tmp):
     """The L-BFGS-B objective of the local refinement, evaluated by the reference itself
     (GPEIOptChooser.py:360-525, GPEIperSecChooser.py:322-434)."""
@@ -374,7 +388,7 @@ def gen_ei_grad(mods, tmp):
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 

@@ -1,25 +1,31 @@
 #!/bin/bash
-# Regenerate the evidence under profiles/ on the GPU box (run through gpurun; outputs under gpurun_out/refresh,
-# then `python scripts/pmc_summary.py r01_c3 ...` and copies are done on the build side).
+# Regenerate the evidence under profiles/ on the GPU box (run through gpurun; raw outputs under gpurun_out/refresh,
+# the small summaries are written to profiles/ by scripts/pmc_summary.py and copied back with gpurun_out/).
+#   gpurun -- 'bash scripts/refresh_profiles.sh r02'
 set -u
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --no-cpu-baseline --skip-extras"
 # kernel trace + stats (no counters)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
-# HBM counters, separate passes
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 2 --warmup 1 > $O/stats.log 2>&1
+# HBM counters, separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > /dev/null 2>&1
+# SQ / TCC counters of the dominant kernels (separate passes: 8 SQ slots, 4 TCC slots)
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU GRBM_GUI_ACTIVE \
+    --kernel-include-regex "k_predict_gemm|k_cov" --output-format csv -d $O/sq1 -- $B --steps 1 --warmup 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
+    --kernel-include-regex "k_predict_gemm|k_cov" --output-format csv -d $O/sq2 -- $B --steps 1 --warmup 0 > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-include-regex "k_predict_gemm|k_cov" --output-format csv -d $O/tcc -- $B --steps 1 --warmup 0 > /dev/null 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
-cp $(find $O/fetch -name "*counter_collection.csv" | head -1) $O/fetch.csv
-cp $(find $O/write -name "*counter_collection.csv" | head -1) $O/write.csv
-rm -rf $O/stats $O/fetch $O/write
+for n in fetch write sq1 sq2 tcc; do cp $(find $O/$n -name "*counter_collection.csv" | head -1) $O/$n.csv 2>/dev/null; done
+rm -rf $O/stats $O/fetch $O/write $O/sq1 $O/sq2 $O/tcc
 cd $R
 mkdir -p profiles
-python scripts/pmc_summary.py r01_c3 $O/kernel_stats.csv $O/fetch.csv $O/write.csv
-cp profiles/r01_c3_rocprof_summary.json $O/
-# bench lines (the c3 line reads the summary written above for roofline.traffic)
-python bench.py 2>/dev/null | tail -1 > $O/r01_c3_bench_line.json
-for w in c2 c4 c5; do python bench.py --workload $w 2>/dev/null | tail -1 > $O/r01_${w}_bench_line.json; done
-head -c 600 $O/r01_c3_bench_line.json; echo
+python scripts/pmc_summary.py ${TAG}_c3 $O/kernel_stats.csv $O/fetch.csv $O/write.csv $O/sq1.csv $O/sq2.csv $O/tcc.csv
+cp profiles/${TAG}_c3_rocprof_summary.json profiles/${TAG}_c3_sq_pmc.json $O/ 2>/dev/null
+cp $O/kernel_stats.csv $O/${TAG}_c3_kernel_stats.csv
+head -c 400 profiles/${TAG}_c3_sq_pmc.json; echo

@@ -8,6 +8,7 @@ from __future__ import absolute_import, print_function
 import numpy as np
 import numpy.random as npr
 
+from .. import hostgp
 from .. import util
 from ..helpers import log
 from ._base import GPEIBase
@@ -41,8 +42,20 @@ class GPEIChooser(GPEIBase):
         comp, cand, pend, vals = self._split(grid, values, candidates, pending, complete)
 
         if self.mcmc_iters <= 0:
-            raise NotImplementedError("mcmc_iters=0 (ML-II hyper optimisation, gp.py:181-292) is outside "
-                                      "the GPU hot path; use mcmc_iters >= 1")
+            # ML-II point estimate instead of MCMC (:157-175): optimise the hypers on the host, fall
+            # back to the defaults if that fails, then score the grid once -- the same GPU call with
+            # a single hyper row (argmax of a one-column mean == argmax(ei))
+            try:
+                self.mean, self.amp2, self.noise, self.ls = hostgp.optimize_hypers(comp, vals)
+            except Exception:
+                self.ls = np.ones(self.D)
+                self.amp2 = np.std(vals)
+                self.noise = 1e-3
+            self._log_hypers()
+            randn = [npr.randn(pend.shape[0], self.pending_samples)] if pend.shape[0] > 0 else []
+            best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand, vals, self.current_hyper_row()[None, :],
+                                                 randn=randn)
+            return int(candidates[best])
         # The reference alternates "sample hypers" and "compute_ei" (:145-151).
         # Without pending experiments compute_ei consumes no random numbers, so
         # drawing all H samples first and scoring them in one GPU call is the

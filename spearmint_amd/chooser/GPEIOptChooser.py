@@ -161,7 +161,9 @@ class GPEIOptChooser(GPEIBase):
         cand2 = np.vstack((np.random.randn(10, comp.shape[1]) * 0.001 + comp[best_comp, :], cand))
 
         if self.mcmc_iters <= 0:
-            raise NotImplementedError("mcmc_iters=0 (ML-II hyper optimisation) is outside the GPU hot path")
+            raise NotImplementedError("mcmc_iters=0: the reference's own branch (GPEIOptChooser.py:300-321) cannot run -- it passes "
+                                      "(comp, vals, True) where grad_optimize_ei expects (comp, pend, vals) and dies with a "
+                                      "ValueError; use GPEIChooser for ML-II hypers or mcmc_iters >= 1")
 
         if self.needs_burnin:
             for it in range(self.burnin):

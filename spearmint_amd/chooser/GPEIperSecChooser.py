@@ -180,7 +180,8 @@ class GPEIperSecChooser(GPEIBase):
         cand2 = np.vstack((np.random.randn(10, comp.shape[1]) * 0.001 + comp[best_comp, :], cand))
 
         if self.mcmc_iters <= 0:
-            raise NotImplementedError("mcmc_iters=0 is outside the GPU hot path")
+            raise NotImplementedError("mcmc_iters=0: the reference's own branch (GPEIperSecChooser.py:243-281) cannot run -- it reads "
+                                      "overall_ei before assigning it (UnboundLocalError); use mcmc_iters >= 1")
 
         if self.needs_burnin:
             for it in range(self.burnin):

@@ -65,6 +65,76 @@ def data_logprob(x, y, mean, amp2, noise, ls):
     return -np.sum(np.log(np.diag(chol))) - 0.5 * np.dot(resid, sol)
 
 
+def optimize_hypers(comp, vals):
+    """ML-II point estimate of (mean, amp2, noise, ls) -- the ``mcmc_iters=0`` branch of the
+    reference (gp.GP.optimize_hypers, gp.py:181-292, called from GPEIChooser.py:158-160).
+    Host-side by design: it runs once per ``next`` and is not on the EI hot path.
+
+    Restated exactly, including what is peculiar about it: the mean is pinned to mean(vals); the
+    search runs in log space from (log std(vals), log 1e-3, log 1) under the box
+    [-10, 10]^2 x [-10, 5]^D; and the length-scale entries of the gradient are the reference's own
+    expression (:256-258), which is not the derivative of the objective -- L-BFGS-B is fed the same
+    numbers, so it lands on the same point the reference does."""
+    import scipy.optimize as spo
+    n, dims = comp.shape
+    mean = np.mean(vals)
+    diffs = vals - mean
+    eye = np.eye(n)
+    memo = {}
+
+    def jittered_cholesky(covmat):
+        jitter = 1e-8
+        while True:
+            if jitter > 100000:
+                return spla.cholesky(eye)
+            try:
+                return spla.cholesky(covmat + jitter * eye, lower=True)
+            except ValueError:          # numpy.linalg.LinAlgError is a ValueError
+                jitter = jitter * 1.1
+
+    def factor(amp2, noise, ls):
+        if ("corr" not in memo or memo["amp2"] != amp2 or memo["noise"] != noise
+                or np.any(memo["ls"] != ls)):
+            corr = matern52(ls, comp)
+            grad_corr = matern52_grad_wrt_first(ls, comp, comp)
+            covmat = amp2 * (corr + 1e-6 * eye) + noise * eye
+            memo.update(corr=corr, grad_corr=grad_corr, chol=jittered_cholesky(covmat),
+                        amp2=amp2, noise=noise, ls=ls)
+        return memo["chol"], memo["corr"], memo["grad_corr"]
+
+    def unpack(h):
+        return np.exp(h[0]), np.exp(h[1]), np.exp(h[2:])
+
+    def nlogprob(h):
+        amp2, noise, ls = unpack(h)
+        chol = factor(amp2, noise, ls)[0]
+        solve = spla.cho_solve((chol, True), diffs)
+        return -(-np.sum(np.log(np.diag(chol))) - 0.5 * np.dot(diffs, solve))
+
+    def grad_nlogprob(h):
+        amp2, noise, ls = unpack(h)
+        chol, corr, grad_corr = factor(amp2, noise, ls)
+        solve = spla.cho_solve((chol, True), diffs)
+        inv_cov = spla.cho_solve((chol, True), eye)
+        jac = np.outer(solve, solve) - inv_cov
+        grad = np.zeros(dims + 2)
+        grad[0] = 0.5 * np.trace(np.dot(jac, corr + 1e-6 * eye)) * amp2
+        grad[1] = 0.5 * np.trace(np.dot(jac, eye)) * noise
+        for dd in range(dims):
+            grad[dd + 2] = 1 * np.trace(np.dot(jac, -amp2 * grad_corr[:, :, dd] * comp[:, dd][:, np.newaxis]
+                                               / (np.exp(ls[dd])))) * np.exp(ls[dd])
+        return -grad
+
+    start = np.zeros(dims + 2)
+    start[0] = np.log(np.std(vals))
+    start[1] = np.log(1e-3)
+    start[2:] = np.log(np.ones(dims))
+    bounds = [(-10, 10), (-10, 10)] + [(-10, 5)] * dims
+    best = spo.fmin_l_bfgs_b(nlogprob, start, grad_nlogprob, args=(), bounds=bounds, disp=0)[0]
+    amp2, noise, ls = unpack(best)
+    return mean, amp2, noise, ls
+
+
 class PointModel(object):
     """Posterior at ONE hyper draw, factorised once, for evaluating EI and its
     gradient at a handful of points during local refinement."""

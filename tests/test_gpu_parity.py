@@ -450,3 +450,18 @@ def test_two_stream_mode_is_bit_identical(eng):
         eng.set_option("kstar_budget_bytes", 0)
     assert a[0] == b[0] and np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
     assert ap[0] == bp[0] and np.array_equal(ap[3], bp[3])
+
+
+def test_gpei_chooser_ml2_hypers_on_gpu(golden_dir, tmp_path):
+    """mcmc_iters=0 (ML-II point estimate, gp.py:181-292): same hypers and proposal as the reference.
+    The optimiser drives the length scales to its lower bound exp(-10), an extreme the K build must survive."""
+    from spearmint_amd.chooser import GPEIChooser
+    g = _g(golden_dir, "chooser_next_ml2.npz")
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=0")
+    npr.seed(5)
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert job == int(g["job"])
+    assert np.allclose(np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)), g["hyper"], rtol=1e-6)
+    comp, cand = g["grid"][g["complete"]], g["grid"][g["candidates"]]
+    ref = orc.ei_over_hypers(comp, cand, g["values"][g["complete"]], g["hyper"][None, :])
+    assert_ei_close(ch.last_overall_ei, ref, rtol=1e-6)

@@ -304,3 +304,19 @@ def test_unpickle_reads_python2_state(tmp_path):
     p.write_bytes(py2)
     st = unpickle(str(p))
     assert np.allclose(st["ls"], [1.0, 0.1])
+
+
+def test_gpei_next_ml2_hypers_matches_reference(golden_dir, tmp_path):
+    """mcmc_iters=0: ML-II hyper optimisation on the host (gp.py:181-292), one-row EI grid."""
+    g = _g(golden_dir, "chooser_next_ml2.npz")
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=0")
+    eng = OracleEngine(); ch._eng = eng
+    npr.seed(5)
+    job = ch.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    assert job == int(g["job"])
+    assert np.allclose(np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)), g["hyper"], rtol=1e-6)
+    assert eng.calls == [("ei_grid", len(g["candidates"]), 1)]
+    for mod in (GPEIOptChooser, GPEIperSecChooser):      # the reference's own branches raise there
+        c2 = mod.init(str(tmp_path), "mcmc_iters=0"); c2._eng = OracleEngine()
+        with pytest.raises(NotImplementedError):
+            c2.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
