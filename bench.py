@@ -193,7 +193,7 @@ def main():
     torch = None
     tdev = None
     try:
-        import torch  # plumbing only: barrier / all-reduce / device sync
+        import torch  # plumbing only: rendezvous, barrier, the all-gather of the 16-byte records, device sync
     except ImportError:
         if world > 1:
             raise
@@ -252,7 +252,7 @@ def main():
             e.factor()
             e.ei_run(fl)
             idx, val = e.best()
-            out = spx_dist.allreduce_best(val, idx, device=tdev)
+            out = spx_dist.exchange_best(val, idx, device=tdev)
         sync()
         return max_over_ranks(time.perf_counter() - t0), out
 

@@ -6,11 +6,8 @@ the only cross-candidate step of the reference is
 ``np.argmax(np.mean(overall_ei, axis=1))`` (GPEIChooser.py:153).  So rank r
 owns the contiguous candidate rows [lo_r, hi_r) of the grid, replicates the
 (tiny) observations and hyper draws, and the ranks exchange exactly one
-record each -- (best mean EI, global index) -- in ONE all-reduce:
-
-    buf = zeros(P, 2); buf[rank] = (value, index); all_reduce(buf, SUM)
-
-Adding zeros is exact, so after the all-reduce every rank holds all P records
+record each -- {best mean EI (fp64), global index (int64)}, 16 bytes -- in ONE
+all-gather, after which every rank holds all P records
 bit-for-bit (a MAX all-reduce on a packed key would lose mantissa bits; RCCL
 has no MAXLOC).  The final pick applies numpy's argmax rule: first NaN wins,
 else the largest value, ties to the lowest global index -- contiguous shards
@@ -33,10 +30,10 @@ def shard_bounds(M, world_size, rank):
 def pick_best(records):
     """numpy-argmax rule over (value, global_index) records.
 
-    records: array (P, 2) float64; index < 0 marks an empty shard."""
+    records: P pairs (value, index); index < 0 marks an empty shard."""
     best_v, best_i = None, -1
-    for v, i in np.asarray(records, dtype=np.float64):
-        i = int(i)
+    for v, i in records:
+        v, i = float(v), int(i)
         if i < 0:
             continue
         if best_i < 0:
@@ -52,8 +49,12 @@ def pick_best(records):
     return best_i, (float(best_v) if best_i >= 0 else float("nan"))
 
 
-def allreduce_best(local_value, local_index, device=None, group=None):
-    """One all-reduce; returns (global_index, value), identical on every rank.
+def exchange_best(local_value, local_index, device=None, group=None):
+    """The one collective of the path: every rank contributes its 16-byte record {best mean EI
+    (float64), global index (int64)} to ONE all-gather (P x 16 bytes; RCCL over xGMI with backend
+    "nccl"), then applies the same numpy-argmax reduction to the gathered table.  Returns
+    (global_index, value), identical on every rank.  The record travels as raw bytes, so the index
+    is exact over the whole int64 range.
 
     Without an initialised process group (single process) it is the identity."""
     try:
@@ -64,12 +65,16 @@ def allreduce_best(local_value, local_index, device=None, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return int(local_index), float(local_value)
     P = dist.get_world_size(group)
-    r = dist.get_rank(group)
-    buf = torch.zeros((P, 2), dtype=torch.float64, device=device)
-    buf[r, 0] = float(local_value)
-    buf[r, 1] = float(local_index)      # exact below 2**53
-    if np.isnan(local_value):
-        # NaN + 0 stays NaN, which is what we want for the value column
-        pass
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    return pick_best(buf.cpu().numpy())
+    rec = np.zeros(1, dtype=[("val", "<f8"), ("idx", "<i8")])
+    rec["val"][0] = local_value
+    rec["idx"][0] = local_index
+    mine = torch.from_numpy(rec.view(np.uint8).copy())
+    if device is not None:
+        mine = mine.to(device)
+    table = torch.empty(16 * P, dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(table, mine, group=group)
+    got = table.cpu().numpy().view([("val", "<f8"), ("idx", "<i8")])
+    return pick_best([(r["val"], r["idx"]) for r in got])
+
+
+allreduce_best = exchange_best   # round-1 name

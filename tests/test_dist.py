@@ -1,4 +1,4 @@
-"""Candidate sharding + the single all-reduce, on CPU with gloo (world_size 2)."""
+"""Candidate sharding + the single collective (all-gather of 16-byte records), on CPU with gloo (world_size 2)."""
 import os
 import socket
 
@@ -46,21 +46,21 @@ def _worker(rank, world, port, q):
     import torch.distributed as tdist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     tdist.init_process_group("gloo", rank=rank, world_size=world)
-    # a fixed global EI vector; each rank scores its shard and the all-reduce picks the winner
+    # a fixed global EI vector; each rank scores its shard and the all-gather + numpy-argmax rule picks the winner
     v = np.random.RandomState(123).rand(1001)
     v[700] = v[100] = 2.0                      # tie across shards -> index 100 must win
     lo, hi = sd.shard_bounds(v.shape[0], world, rank)
     j = int(np.argmax(v[lo:hi]))
-    out1 = sd.allreduce_best(v[lo + j], lo + j)
+    out1 = sd.exchange_best(v[lo + j], lo + j)
     v2 = v.copy(); v2[900] = np.nan             # NaN in the last shard wins
     j2 = int(np.argmax(v2[lo:hi]))
-    out2 = sd.allreduce_best(v2[lo + j2], lo + j2)
+    out2 = sd.exchange_best(v2[lo + j2], lo + j2)
     q.put((rank, out1, out2))
     tdist.barrier()
     tdist.destroy_process_group()
 
 
-def test_allreduce_best_gloo_world2():
+def test_exchange_best_gloo_world2():
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -79,7 +79,7 @@ def test_allreduce_best_gloo_world2():
 
 
 def test_allreduce_without_group_is_identity():
-    assert sd.allreduce_best(1.5, 42) == (42, 1.5)
+    assert sd.exchange_best(1.5, 42) == (42, 1.5)
 
 
 def test_strong_scaling_grid_does_not_depend_on_world_size():

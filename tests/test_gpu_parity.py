@@ -218,7 +218,7 @@ def test_chunking_and_draw_grouping_do_not_change_bits(eng):
 
 
 def test_sharding_is_exact(eng):
-    """Two contiguous shards + the all-reduce rule == the single-GPU answer, bit for bit."""
+    """Two contiguous shards + the argmax rule of the collective == the single-GPU answer, bit for bit."""
     comp, cand, vals, hypers = synthetic_problem(150, 2501, 5, 4, 28)
     idx, val, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
     recs, parts = [], []
