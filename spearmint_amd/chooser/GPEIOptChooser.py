@@ -32,7 +32,7 @@ class GPEIOptChooser(GPEIBase):
     max_ls = 2
 
     def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
-                 noiseless=False, burnin=100, grid_subset=20, use_multiprocessing=True, **kw):
+                 noiseless=False, burnin=100, grid_subset=20, use_multiprocessing=True, rescore_grid=0, **kw):
         GPEIBase.__init__(self, expt_dir, covar=covar, mcmc_iters=mcmc_iters,
                           pending_samples=pending_samples, noiseless=noiseless, **kw)
         self.stats_file = os.path.join(expt_dir, self.__module__ + "_hyperparameters.txt")
@@ -42,6 +42,7 @@ class GPEIOptChooser(GPEIBase):
         # accepted for command-line compatibility; the refinement below is serial
         # (a fork-based Pool cannot share a HIP context)
         self.use_multiprocessing = _as_bool(use_multiprocessing)
+        self.rescore_grid = _as_bool(rescore_grid)   # 1: score [grid; refined] again in the second pass, as the reference does
         self.hyper_samples = []
 
     # -- state -----------------------------------------------------------------
@@ -184,10 +185,17 @@ class GPEIOptChooser(GPEIBase):
         keep = np.argsort(mean1)[-self.grid_subset:]
         refined = self._refine(cand2[keep, :], comp, vals, pend)
 
-        # pass 2 over grid + refined points (:292-299)
-        cand_all = np.vstack((cand, refined))
+        # pass 2 over grid + refined points (:292-299).  The reference scores the whole grid again; a
+        # candidate's EI does not depend on which other candidates share the call (bit for bit: the
+        # sharding tests rely on it), so the grid rows keep their pass-1 values and only the refined
+        # points are scored.  rescore_grid=1 runs the literal second pass instead.
         randn = self._fantasy_normals(pend) if pend.shape[0] > 0 else None
-        best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand_all, vals, rows, randn=randn)
+        if self.rescore_grid:
+            cand_all = np.vstack((cand, refined))
+            best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand_all, vals, rows, randn=randn)
+        else:
+            _, mean_ref, _ = self.ei_over_hypers_gpu(comp, pend, refined, vals, rows, want_draws=False, randn=randn)
+            best = int(np.argmax(np.concatenate((mean1[10:], mean_ref))))
         if best >= numcand:
-            return (int(numcand), cand_all[best, :])
+            return (int(numcand), refined[best - numcand, :])
         return int(candidates[best])

@@ -204,9 +204,17 @@ class GPEIperSecChooser(GPEIBase):
         keep = np.argsort(mean1)[-self.grid_subset:]
         refined = self._refine(cand2[keep, :], comp, vals, durs)
 
-        cand_all = np.vstack((cand, refined))
-        best, _ = self.ei_per_s_over_hypers_gpu(comp, pend, cand_all, vals, durs)
+        # second pass (:233-236).  Without pending jobs only the refined points are new: the grid rows keep
+        # their first-pass values (a candidate's result does not depend on the others of the call).  With
+        # pending jobs the reference draws FRESH fantasy normals in every pass (:523), so the grid is scored
+        # again, as it does.
+        if pend.shape[0] > 0:
+            cand_all = np.vstack((cand, refined))
+            best, _ = self.ei_per_s_over_hypers_gpu(comp, pend, cand_all, vals, durs)
+        else:
+            _, mean_ref = self.ei_per_s_over_hypers_gpu(comp, pend, refined, vals, durs)
+            best = int(np.argmax(np.concatenate((mean1[10:], mean_ref))))
         self.dump_hypers()
         if best >= numcand:
-            return (int(numcand), cand_all[best, :])
+            return (int(numcand), refined[best - numcand, :])
         return int(candidates[best])
