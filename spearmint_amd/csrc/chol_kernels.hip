@@ -10,10 +10,13 @@
 // Left-looking, one block column k at a time (two launches per k):
 //   k_chol_diag   1 workgroup / draw : S = K_kk - L_k,:k L_k,:k^T (MFMA, panels
 //                 staged in LDS); the 64x64 block is factored with 16x16
-//                 sub-blocks: each diagonal sub-block by one wavefront with its
-//                 rows in registers and the pivot column broadcast lane-to-lane
-//                 (v_readlane), sub-panel and trailing updates by MFMA; then the
-//                 inverse of the block by block forward substitution (MFMA).
+//                 sub-blocks: each diagonal sub-block is factored and inverted by
+//                 one wavefront on the matrix pipe (factor16_mfma: a rank-1 MFMA
+//                 per pivot), sub-panel and trailing updates by MFMA; the inverse
+//                 of the block by block forward substitution (MFMA).
+//   k_lean_step   (log-likelihood path) one right-looking update step for every
+//                 trailing tile, the diagonal block factored by the workgroup
+//                 that owns it.
 //   k_chol_panel  1 workgroup / (row block > k, draw):
 //                 L_rk = (K_rk - L_r,:k L_k,:k^T) L_kk^-T          (MFMA)
 // k_trinv: W = L^-1 by block columns (one launch), stored transposed
