@@ -154,3 +154,22 @@ def test_c5_full_half_million_candidates_per_second(eng):
     sub = np.concatenate((top, np.setdiff1d(rnd, top)))
     ref = orc.ei_per_s_over_hypers(comp, cand[sub], vals, log_durs, hypers, th)
     check_winner(mean, idx, draws[sub], ref, sub, topk)
+
+
+# ---- sizes beyond BASELINE.json (the reference has no limits of its own; these pin ours) ----------
+@pytest.mark.parametrize("N,M,D,H,seed", [(4096, 1500, 48, 2, 8100), (8192, 600, 16, 1, 8200), (300, 900, 300, 2, 8300),
+                                          (500, 700, 6, 50, 8400)])
+def test_large_observation_counts_dimensions_and_draw_counts(eng, N, M, D, H, seed):
+    """N = 4096 and 8192 observations (64 / 128 block columns), 300 input dimensions (10 Gram chunks),
+    50 hyper draws in one call -- against the oracle, every value."""
+    comp, cand, vals, hypers = synthetic_problem(N, M, D, H, seed)
+    idx, _, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    ref = orc.ei_grid_chunked(comp, cand, vals, hypers)
+    assert rel_err(draws, ref) <= 1e-6
+    assert idx == orc.choose(ref)
+    assert np.array_equal(mean, np.mean(draws, axis=1))
+    eng.set_observations(comp, vals); eng.set_hypers(hypers[:min(H, 3)])
+    lp = eng.gp_logprob()
+    for h in range(len(lp)):
+        lref = orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:])
+        assert np.isclose(lp[h], lref, rtol=1e-10)
