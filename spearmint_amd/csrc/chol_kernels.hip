@@ -167,9 +167,16 @@ __device__ __forceinline__ void inv_block_row(const double* S, double* XT, const
     for (int r = 0; r < 4; ++r) XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
 }
 
+#ifdef SPX_DIAG_STAMPS   // dev: phase time stamps for scripts/ubench_diag.hip
+__shared__ long long g_stamp[32];
+#define STAMP(i) do { if (threadIdx.x == 0) g_stamp[i] = clock64(); } while (0)
+#else
+#define STAMP(i)
+#endif
 __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, int* info_h, int pivot_base,
                                            double* __restrict__ Lkk, size_t ldl, double* __restrict__ Dk)
 {
+    STAMP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     int bad = 0;
@@ -191,7 +198,9 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         } else if (wave < b) {
             inv_block_row(S, XT, T16, b - 1, wave - 1, g, li);   // row b-1 of the inverse, block column wave-1
         }
+        STAMP(1 + 4 * b);
         __syncthreads();
+        STAMP(2 + 4 * b);
         // (b) sub-panel: rows of tile ti = b+1+wave, P <- P Linv16^T
         {
             const int ti = b + 1 + wave;
@@ -208,6 +217,7 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
             }
         }
         __syncthreads();
+        STAMP(3 + 4 * b);
         // (c) trailing update of the sub-blocks (ti, tj), b < tj <= ti
         {
             int idx = 0;
@@ -228,12 +238,14 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                 }
         }
         if (b < 3) __syncthreads();   // round 3 has no sub-panel / trailing work: nothing was written
+        STAMP(4 + 4 * b);
     }
     if (wave == 0 && lane == 0 && bad) {
         if (*info_h == 0) *info_h = bad;
     }
     if (wave < 3) inv_block_row(S, XT, T16, 3, wave, g, li);   // last row of the inverse
     __syncthreads();
+    STAMP(17);
     // write L_kk (upper part zero) and its inverse, 16 bytes per lane
     for (int idx = threadIdx.x; idx < NB * NB / 2; idx += 256) {
         const int row = idx >> 5, col = (idx & 31) * 2;
@@ -245,6 +257,7 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         *reinterpret_cast<d2*>(Lkk + (size_t)row * ldl + col) = lv;
         *reinterpret_cast<d2*>(Dk + row * NB + col) = xv;
     }
+    STAMP(18);
 }
 
 // ---------------------------------------------------------------------------
