@@ -353,7 +353,11 @@ void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, con
                          const double* dkt, int S, const double* gammaS, const double* alphaS,
                          const double* bests, double* uvec)
 {
-    hipLaunchKernelGGL(k_point_finish, dim3(nh, P), dim3(256), (size_t)3 * S * sizeof(double), s, Xs, hyp,
+    const size_t lds = (size_t)3 * S * sizeof(double);   // up to 96 KB at S = 4096: above the 64 KB default limit
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_finish),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_point_finish, dim3(nh, P), dim3(256), lds, s, Xs, hyp,
                        htab, alpha, kvec, dkdr2, tvec, zvec, x, best, out, N, Np, D, Dp, P, nh, kt, dkt, S,
                        gammaS, alphaS, bests, uvec);
 }
