@@ -165,6 +165,46 @@ def strong_problem(cfg):
     return prob, prob[0], prob[2], prob[3]
 
 
+def main_in_process(args):
+    """The weak-scaling headline through ONE multi-device handle: n x 200 000 candidates of one grid, sharded by
+    the library over n GPUs driven from this process; the collective is libspx's own ncclAllGather."""
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    n = len(devs)
+    w = WORKLOADS[args.workload]
+    N, M, D, H = w["N"], w["M"], w["D"], w["H"]
+    flags = FLAG_PER_SEC if w["per_sec"] else 0
+    prob, comp, vals, hypers, shard0 = weak_problem(w, 0)
+    cand = np.vstack([shard0] + [weak_problem(w, r)[4] for r in range(1, n)])
+    eng = Engine(devices=devs)
+    eng.set_observations(comp, vals)
+    eng.set_candidates(cand)
+    eng.set_hypers(hypers)
+    if w["per_sec"]:
+        eng.set_time_model(prob[4], prob[5])
+
+    def run(nsteps):
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            eng.factor()
+            eng.ei_run(flags)
+            out = eng.best()
+        return time.perf_counter() - t0, out
+
+    if args.warmup:
+        run(args.warmup)
+    dt, best = run(args.steps)
+    print(json.dumps({
+        "metric": "EI candidate evaluations per second (N_cand x mcmc_iters / wall time)",
+        "value": n * float(M) * H * args.steps / dt, "unit": "EI evals/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": w["desc"], "N_obs": N, "candidates_per_gpu": M, "D": D, "mcmc_iters": H,
+                   "per_sec": w["per_sec"], "mode": "one process, one multi-device handle (spx_create_multi)",
+                   "devices": devs, "transport": eng.transport()},
+        "best_index": best[0], "best_ei": best[1]}))
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,7 +222,14 @@ def main():
     ap.add_argument("--kstar-budget-mb", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="0 = library default")
     ap.add_argument("--gemm-waves", type=int, default=0, help="predict GEMM variant (see predict_kernels.hip)")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process, one libspx handle over --gpus devices (spx_create_multi: host thread per GPU, "
+                         "RCCL all-gather inside the library) instead of one process per GPU; what the unmodified "
+                         "single-process Spearmint driver uses with --method-args=ndev=N")
+    ap.add_argument("--devices", default="", help="with --in-process: comma-separated device ids (default 0..gpus-1)")
     args = ap.parse_args()
+    if args.in_process:
+        return main_in_process(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

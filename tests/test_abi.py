@@ -72,3 +72,47 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|import_module\(.oracle|oracle/", txt, re.M), \
                     os.path.join(d, f)
+
+
+def test_multi_handle_creation_is_lazy_and_checked(lib):
+    """spx_create_multi: argument checks, and -- with repeated device ids, which use the host transport --
+    no GPU is touched until the first call that needs one (the chooser is constructed before a fork)."""
+    with pytest.raises(ValueError):
+        engine.Engine(devices=[])
+    import ctypes
+    h = ctypes.c_void_p()
+    assert lib.spx_create_multi(None, 2, ctypes.byref(h)) == engine.SPX_ERR_ARG
+    arr = (ctypes.c_int32 * 2)(0, -1)
+    assert lib.spx_create_multi(arr, 2, ctypes.byref(h)) == engine.SPX_ERR_ARG
+    eng = engine.Engine(devices=[0, 0])
+    assert eng.transport() == "host" and eng.devices == [0, 0]
+    with pytest.raises(ValueError):
+        eng.ei_run()                                   # nothing set yet: same check as a single handle
+    if engine.device_count() == 0:
+        with pytest.raises(engine.SpxError):           # and no CPU fallback behind the multi handle either
+            eng.ei_grid([[0.1, 0.2], [0.3, 0.4]], [1.0, 2.0], [[0.5, 0.5]], [[0.0, 1e-3, 1.0, 1.0, 1.0]])
+    eng.close()
+    single = engine.Engine(0)
+    assert single.transport() == "none"
+    single.close()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/spx.h is the boundary a C / cgo / JNI caller would bind: it must compile as C99 on its own."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_spx.c"
+    src.write_text('#include "spx.h"\n'
+                   "int probe(void) {\n"
+                   "  spx_handle* h = 0; int devs[2] = {0, 1}; int64_t idx = 0; double val = 0.0, f = 0.0, g[2];\n"
+                   "  int rc = spx_create_multi(devs, 2, &h);\n"
+                   "  rc |= spx_ei_grad_batch(h, g, 1, &f, g);\n"
+                   "  rc |= spx_get_best(h, &idx, &val);\n"
+                   "  spx_destroy(h);\n"
+                   "  return rc + SPX_TRANSPORT_RCCL + SPX_FLAG_PER_SEC;\n"
+                   "}\n")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])

@@ -278,3 +278,26 @@ def test_ablation_variants_are_not_in_the_shipped_library(eng):
     assert np.array_equal(b[3], c[3]) and b[0] == c[0]
     big = c[3] >= 1e-280          # the far EI tail amplifies rounding differences (u^2 ~ 1e3)
     assert a[0] == c[0] and np.max(np.abs(a[3][big] - c[3][big]) / c[3][big]) <= 1e-7
+
+
+def test_bench_in_process_mode_matches_the_default_mode(eng):
+    """bench.py --in-process: the weak-scaling headline through one multi-device handle (the RCCL path of
+    libspx; here a communicator of one device) must pick the same candidate as the default mode."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--in-process", "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--workload", "c2"]
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["config"]["transport"] == "rccl" and out["n_gpus"] == 1
+    w = bench.WORKLOADS["c2"]
+    _, comp, vals, hypers, s0 = bench.weak_problem(w, 0)
+    idx, val, _, _ = eng.ei_grid(comp, vals, s0, hypers)
+    assert (out["best_index"], out["best_ei"]) == (idx, val)
+    # two engines on the one GPU (host transport): rank 1's shard appended
+    cmd = cmd[:3] + ["--devices", "0,0"] + cmd[3:]
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
+    s1 = bench.weak_problem(w, 1)[4]
+    idx, val, _, _ = eng.ei_grid(comp, vals, np.vstack((s0, s1)), hypers)
+    assert out["config"]["transport"] == "host" and (out["best_index"], out["best_ei"]) == (idx, val)
