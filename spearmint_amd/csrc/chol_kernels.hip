@@ -174,7 +174,8 @@ __shared__ long long g_stamp[32];
 #define STAMP(i)
 #endif
 __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, int* info_h, int pivot_base,
-                                           double* __restrict__ Lkk, size_t ldl, double* __restrict__ Dk)
+                                           double* __restrict__ Lkk, size_t ldl, double* __restrict__ Dk,
+                                           double* __restrict__ diag_out = nullptr)
 {
     STAMP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -246,16 +247,21 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
     if (wave < 3) inv_block_row(S, XT, T16, 3, wave, g, li);   // last row of the inverse
     __syncthreads();
     STAMP(17);
-    // write L_kk (upper part zero) and its inverse, 16 bytes per lane
+    // write L_kk (upper part zero) and its inverse, 16 bytes per lane; the log-likelihood path only
+    // needs the diagonal of L_kk (diag_out) besides the inverse
+    if (diag_out && threadIdx.x < NB) diag_out[threadIdx.x] = S[threadIdx.x * LDP + threadIdx.x];
     for (int idx = threadIdx.x; idx < NB * NB / 2; idx += 256) {
         const int row = idx >> 5, col = (idx & 31) * 2;
-        d2 lv, xv;
-        lv[0] = (col <= row) ? S[row * LDP + col] : 0.0;
-        lv[1] = (col + 1 <= row) ? S[row * LDP + col + 1] : 0.0;
+        d2 xv;
         xv[0] = (col <= row) ? XT[col * LDP + row] : 0.0;
         xv[1] = (col + 1 <= row) ? XT[(col + 1) * LDP + row] : 0.0;
-        *reinterpret_cast<d2*>(Lkk + (size_t)row * ldl + col) = lv;
         *reinterpret_cast<d2*>(Dk + row * NB + col) = xv;
+        if (Lkk) {
+            d2 lv;
+            lv[0] = (col <= row) ? S[row * LDP + col] : 0.0;
+            lv[1] = (col + 1 <= row) ? S[row * LDP + col + 1] : 0.0;
+            *reinterpret_cast<d2*>(Lkk + (size_t)row * ldl + col) = lv;
+        }
     }
     STAMP(18);
 }
@@ -405,22 +411,62 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 }
 
 // ---------------------------------------------------------------------------
-// k_lean_step: one step of the right-looking factorisation the log-likelihood path uses (a handful of
-// draws cannot fill the chip with the left-looking panel, whose k steps per tile run sequentially
-// in one workgroup).  Launch k applies update step k-1 to every remaining lower tile,
+// Log-likelihood path (spx_gp_logprob, up to 32 draws): right-looking factorisation of 64x64 tiles.
+//
+// Storage.  The matrix of a draw is kept TILE-MAJOR: tile (I, J) at ((I nblk + J) * 4096) doubles,
+// and inside a tile in MFMA accumulator order, as 8 planes of [256 threads][2 doubles]: value
+// q = 4 nt + r of thread t = 64 wave + lane -- the element (row 16 wave + (lane >> 4) + 4 r, column
+// 16 nt + (lane & 15)) -- sits at ((q >> 1) * 256 + t) * 2 + (q & 1).  Every kernel below moves a tile
+// with eight 16-byte accesses per thread, each of them 1 KiB contiguous across the wavefront; with a
+// row-major matrix the same accumulator traffic is 8 bytes per lane in 128-byte row segments, and
+// timing-only ablations showed those loads, not the MFMAs, bound the trailing update (DESIGN.md
+// section 8).  k_cov writes the same layout (launch_cov_self, tiled); the right-hand side rows are one
+// more block row.
+//
+// k_lean_step: launch k applies update step k-1 to every remaining lower tile,
 //   A_ij -= L_i,k-1 L_j,k-1^T      for k <= j <= i   (and the right-hand-side rows),
 // one 64-deep MFMA step per tile, in place -- and the workgroup that owns the diagonal tile (k, k),
 // which is thereby complete, goes straight on to factor and invert it (diag_block), so that the
-// serial part of the factorisation (the 64x64 diagonal blocks, ~20 us each) runs beside the bulk of
+// serial part of the factorisation (the 64x64 diagonal blocks, ~15 us each) runs beside the bulk of
 // the update instead of in a launch of its own: two launches per block column (this one and the
-// triangular solve of the panel, k_chol_panel) instead of three, and the update of step k-1 is
-// hidden behind the diagonal block of step k or the other way round.  The steps reach each tile in
-// the order p = 0, 1, ... as in the left-looking kernel, so the factor is bit-identical.
-// Grid (rows, columns, draws) over the trailing tiles; k = 0: only the diagonal workgroup.
-#define LEAN_CH 4   // trailing tiles of one block row handled by one workgroup (the row operand stays in LDS)
-__global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lm, double* __restrict__ Dinv,
-                                                   int* __restrict__ info, double* __restrict__ rhs, int Np,
-                                                   int k)
+// triangular solve of the panel, k_lean_trsm) instead of three.  A workgroup walks up to LEAN_CH
+// tiles of one block row: the row operand stays in LDS, the next tile's operand and accumulator are
+// in flight while the current one computes.  The steps reach each tile in the order p = 0, 1, ... as
+// in the left-looking kernel of the EI path, so the factor is bit-identical.
+// Grid (rows, column chunks, draws) over the trailing tiles; k = 0: only the diagonal workgroup.
+#define LEAN_CH 4
+#define LEAN_TILE (NB * NB)
+
+// a tile in accumulator order <-> the [64][LDP] MFMA operand layout in LDS
+__device__ __forceinline__ void acc_tile_to_lds(const d4 (&t)[4], double* lds, int wave, int g, int li)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = t[nt][r];
+}
+__device__ __forceinline__ void load_tile(const double* __restrict__ tile, d4 (&t)[4])
+{
+    const d2* p = reinterpret_cast<const d2*>(tile) + threadIdx.x;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const d2 lo = p[(2 * nt) * 256], hi = p[(2 * nt + 1) * 256];
+        t[nt] = (d4){lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+__device__ __forceinline__ void store_tile(double* __restrict__ tile, const d4 (&t)[4])
+{
+    d2* p = reinterpret_cast<d2*>(tile) + threadIdx.x;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        p[(2 * nt) * 256] = (d2){t[nt][0], t[nt][1]};
+        p[(2 * nt + 1) * 256] = (d2){t[nt][2], t[nt][3]};
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, double* __restrict__ Dinv,
+                                                   int* __restrict__ info, double* __restrict__ rhs,
+                                                   double* __restrict__ diagL, int Np, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;              // [64][LDP]  L_i,k-1 (or the right-hand-side rows' block k-1); then S
@@ -436,59 +482,46 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lm, d
     const int j0 = k + blockIdx.y * LEAN_CH;
     const int j1 = min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
     if (j0 >= j1) return;
-    double* Lh = Lm + (size_t)h * Np * Np;
-    double* Ar = is_rhs ? rhs + (size_t)h * NB * Np : Lh + (size_t)i * NB * Np;
-    const size_t pb0 = (size_t)(k > 0 ? k - 1 : 0) * NB;
-    auto load_acc = [&](int j, d4 (&acc)[4]) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[nt][r] = Ar[(size_t)(16 * wave + g + 4 * r) * Np + (size_t)j * NB + 16 * nt + li];
-    };
-    d4 acc[4], accn[4];
-    TileRegs tb;
-    load_acc(j0, accn);
+    double* Lh = Lt + (size_t)h * Np * Np;
+    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
+    const int kp = k > 0 ? k - 1 : 0;
+    d4 acc[4], accn[4], tb[4];
+    load_tile(row + (size_t)j0 * LEAN_TILE, accn);
     if (k > 0) {
-        tile_load(Lh + (size_t)j0 * NB * Np + pb0, Np, tb);
-        tile_to_lds(Ar + pb0, Np, A);      // the row operand, once
+        load_tile(Lh + ((size_t)j0 * nblk + kp) * LEAN_TILE, tb);
+        d4 ta[4];
+        load_tile(row + (size_t)kp * LEAN_TILE, ta);
+        acc_tile_to_lds(ta, A, wave, g, li);      // the row operand, once
     }
     for (int j = j0; j < j1; ++j) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = accn[nt];
         if (k > 0) {
-            tile_store(tb, B);
+            acc_tile_to_lds(tb, B, wave, g, li);
             __syncthreads();
             if (j + 1 < j1) {              // the next tile's operand and accumulator fly while this one computes
-                tile_load(Lh + (size_t)(j + 1) * NB * Np + pb0, Np, tb);
-                load_acc(j + 1, accn);
+                load_tile(Lh + ((size_t)(j + 1) * nblk + kp) * LEAN_TILE, tb);
+                load_tile(row + (size_t)(j + 1) * LEAN_TILE, accn);
             }
             mma_tile_64(A, B, acc, wave, g, li, true);
         }
         if (!is_rhs && i == k && j == k) {
             // the serial part of the factorisation (this is the only tile of this workgroup)
-            __builtin_amdgcn_s_setprio(3);
             __syncthreads();           // every wave is done reading A / B
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) A[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = acc[nt][r];
+            acc_tile_to_lds(acc, A, wave, g, li);
             __syncthreads();
-            diag_block(A, B, T16, info + h, k * NB, Lh + (size_t)j * NB * Np + (size_t)j * NB, (size_t)Np,
-                       Dinv + ((size_t)h * nblk + k) * NB * NB);
+            diag_block(A, B, T16, info + h, k * NB, nullptr, 0, Dinv + ((size_t)h * nblk + k) * NB * NB,
+                       diagL + (size_t)h * Np + (size_t)k * NB);
             return;
         }
         if (k == 0) return;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Ar[(size_t)(16 * wave + g + 4 * r) * Np + (size_t)j * NB + 16 * nt + li] = acc[nt][r];
+        store_tile(row + (size_t)j * LEAN_TILE, acc);
         __syncthreads();               // B is rewritten for the next tile
     }
 }
 
-void launch_lean_step(hipStream_t s, double* L, double* Dinv, int* info, double* rhs, int Np, int k, int nh)
+void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int Np, int k,
+                      int nh)
 {
     const int n = Np / NB - k;
     if (n <= 0) return;
@@ -496,7 +529,101 @@ void launch_lean_step(hipStream_t s, double* L, double* Dinv, int* info, double*
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid = (k == 0) ? dim3(1, 1, nh) : dim3(n + (rhs ? 1 : 0), (n + LEAN_CH - 1) / LEAN_CH, nh);
-    hipLaunchKernelGGL(k_lean_step, grid, dim3(256), lds, s, L, Dinv, info, (k == 0) ? nullptr : rhs, Np, k);
+    hipLaunchKernelGGL(k_lean_step, grid, dim3(256), lds, s, Lt, Dinv, info, (k == 0) ? nullptr : rhs, diagL, Np, k);
+}
+
+// L_ik = A_ik L_kk^-T for the tiles below the diagonal block of column k and for the right-hand-side
+// rows (last workgroup): one MFMA tile product, in place.
+__global__ __launch_bounds__(256, 2) void k_lean_trsm(double* __restrict__ Lt, const double* __restrict__ Dinv,
+                                                   double* __restrict__ rhs, int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;              // [64][LDP]
+    double* B = smem + NB * LDP;   // [64][LDP]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.y;
+    const int nblk = Np / NB;
+    const bool is_rhs = blockIdx.x == gridDim.x - 1;
+    const int i = k + 1 + blockIdx.x;
+    double* tile = is_rhs ? rhs + ((size_t)h * nblk + k) * LEAN_TILE
+                          : Lt + (size_t)h * Np * Np + ((size_t)i * nblk + k) * LEAN_TILE;
+    d4 acc[4];
+    load_tile(tile, acc);
+    acc_tile_to_lds(acc, A, wave, g, li);
+    tile_to_lds(Dinv + ((size_t)h * nblk + k) * NB * NB, NB, B);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+    mma_tile_64(A, B, acc, wave, g, li, false);
+    store_tile(tile, acc);
+}
+
+void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs, int Np, int k, int nh)
+{
+    const int nrows = Np / NB - k - 1;
+    const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);   // 67.6 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_trsm),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_lean_trsm, dim3(nrows + 1, nh), dim3(256), lds, s, Lt, Dinv, rhs, Np, k);
+}
+
+// the right-hand-side block row in tile storage: row 0 = vals - mean (0 for pad entries), rows 1..63 = 0
+__global__ __launch_bounds__(256) void k_lean_rhs_init(const double* __restrict__ vals,
+                                                       const double* __restrict__ htab,
+                                                       double* __restrict__ rhs, int N, int Np)
+{
+    const int h = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;      // over [nblk][4096]
+    if (idx >= NB * Np) return;
+    const int J = idx >> 12, e = idx & 4095;
+    const int t = (e >> 1) & 255, q = ((e >> 9) << 1) | (e & 1);   // thread slot, value q = nt * 4 + r
+    const int wave = t >> 6, lane = t & 63, r = q & 3, nt = q >> 2;
+    const int rowi = 16 * wave + (lane >> 4) + 4 * r, col = J * NB + 16 * nt + (lane & 15);
+    double v = 0.0;
+    if (rowi == 0 && col < N) v = vals[col] - htab[h * SPX_HT + 0];
+    rhs[(size_t)h * NB * Np + idx] = v;
+}
+
+void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh)
+{
+    hipLaunchKernelGGL(k_lean_rhs_init, dim3((NB * Np + 255) / 256, nh), dim3(256), 0, s, vals, htab, rhs, N, Np);
+}
+
+// lp = -sum log diag(L) - 0.5 |y|^2 (GPEIChooser.py:284) from the diagonal the diag blocks left in diagL
+// and y = row 0 of the right-hand-side tiles; -inf if not PD
+__global__ __launch_bounds__(256) void k_lean_logprob(const double* __restrict__ diagL,
+                                                      const double* __restrict__ rhs,
+                                                      const int* __restrict__ info,
+                                                      double* __restrict__ out, int N, int Np)
+{
+    __shared__ double red[2][256];
+    const int h = blockIdx.x;
+    double sl = 0.0, sq = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        sl += log(diagL[(size_t)h * Np + i]);
+        // element (row 0, column i): tile i / 64, thread t = i & 15 (wave 0, g 0), value q = 4 nt, nt = (i & 63) >> 4
+        const double gi = rhs[(size_t)h * NB * Np + (size_t)(i >> 6) * LEAN_TILE + ((((i & 63) >> 4) * 2) * 256 + (i & 15)) * 2];
+        sq += gi * gi;
+    }
+    red[0][threadIdx.x] = sl;
+    red[1][threadIdx.x] = sq;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[h] = info[h] ? -__builtin_inf() : (-red[0][0] - 0.5 * red[1][0]);
+}
+
+void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int N,
+                         int Np, int nh)
+{
+    hipLaunchKernelGGL(k_lean_logprob, dim3(nh), dim3(256), 0, s, diagL, rhs, info, out, N, Np);
 }
 
 // ---------------------------------------------------------------------------

@@ -30,7 +30,7 @@ void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad,
                        const double* ls /*[nh][ls_stride]*/, int ls_stride, int nh, double factor,
                        double* xs /*[nh][n_pad][Dp]*/, double* sumsq /*[nh][n_pad]*/);
 void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const double* X2s,
-                     const double* htab, double* K, int N, int Np, int Dp, int nh);
+                     const double* htab, double* K, int N, int Np, int Dp, int nh, bool tiled = false);
 void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                       const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
                       int Dp, int nh);
@@ -42,7 +42,13 @@ void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const 
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh, int updated = 0);
 void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs = nullptr,
                        int right_looking = 0);
-void launch_lean_step(hipStream_t s, double* L, double* Dinv, int* info, double* rhs, int Np, int k, int nh);
+// log-likelihood path, tile-major storage (chol_kernels.hip)
+void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int Np, int k,
+                      int nh);
+void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs, int Np, int k, int nh);
+void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh);
+void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int N,
+                         int Np, int nh);
 void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh);
 void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
                   double* gamma, int N, int Np, int nh);

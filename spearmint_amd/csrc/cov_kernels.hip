@@ -237,12 +237,20 @@ __global__ __launch_bounds__(256, 2) void k_cov(
                     // pad rows (j >= N) are written as 0 (amp_j = 0); a NaN column stays NaN there,
                     // which is harmless: that candidate's result is NaN anyway
                     out[((size_t)h * Np + j) * ldo + c] = amp_j * corr;
-                } else if (MODE == 1) {
+                } else if (MODE == 1 || MODE == 3) {
 #pragma clang fp contract(off)
                     const double eye = (j == c) ? 1.0 : 0.0;
                     double v = amp2 * (corr + 1e-6 * eye) + noise * eye;
                     if (j >= N || c >= N) v = eye;
-                    out[((size_t)h * Np + j) * ldo + c] = v;
+                    if (MODE == 1) {
+                        out[((size_t)h * Np + j) * ldo + c] = v;
+                    } else {
+                        // tile-major, accumulator order inside a 64x64 tile as 8 planes of [256][2]
+                        // (chol_kernels.hip, log-likelihood path): value q = 4 nt + r of thread t
+                        const size_t tile = (size_t)(j >> 6) * (Np >> 6) + (c >> 6);
+                        const int t = ((j >> 4) & 3) * 64 + lane, q = nt * 4 + r;
+                        out[(size_t)h * Np * Np + tile * 4096 + (((q >> 1) * 256 + t) * 2 + (q & 1))] = v;
+                    }
                 } else {
                     // pad rows have alpha == 0 and finite corr
                     colsum[nt] += (amp2 * corr) * av;
@@ -253,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void k_cov(
 
     // MODE 0/1: a workgroup covers `rows_per_wg` rows (a multiple of 128) so that the prologue
     // (column-side fragment and norm loads, ~1-2 us of latency) is amortised over many row tiles
+    // (MODE 3 relies on j0 being a multiple of 16 and c0 of 64: both hold for every launch geometry below)
     const int jbeg = (MODE == 2) ? 0 : blockIdx.y * rows_per_wg;
     const int jend = (MODE == 2) ? Np : min(Np, jbeg + rows_per_wg);
     for (int j0 = jbeg + wave * 16; j0 < jend; j0 += 64) {
@@ -327,9 +336,10 @@ void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const d
 
 // X2s = 2 * Xs (the reference multiplies the second operand by 2, gp.py:50)
 void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const double* X2s,
-                     const double* htab, double* K, int N, int Np, int Dp, int nh)
+                     const double* htab, double* K, int N, int Np, int Dp, int nh, bool tiled)
 {
-    launch_cov_mode<1>(s, Xs, s1, X2s, s1, htab, nullptr, K, N, Np, Np, Dp, nh, Np);
+    if (tiled) launch_cov_mode<3>(s, Xs, s1, X2s, s1, htab, nullptr, K, N, Np, Np, Dp, nh, Np);
+    else launch_cov_mode<1>(s, Xs, s1, X2s, s1, htab, nullptr, K, N, Np, Np, Dp, nh, Np);
 }
 
 void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const double* Cs,

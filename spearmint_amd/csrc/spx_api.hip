@@ -132,7 +132,8 @@ void spx_destroy(spx_handle* h)
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
                           &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
-                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs};
+                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL,
+                          &h->alphaS, &h->pt_u, &h->rec_send, &h->rec_recv, &h->rec_out};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
@@ -295,24 +296,34 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d()));
     // second operand pre-multiplied by 2 (gp.py:50); the row norms it writes are identical
     TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 2.0, h->X2s.d(), h->s1.d()));
-    TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh));
-    // lean: the right-hand side vals - mean rides through the factorisation as an extra row block
-    // (k_chol_panel, rhs), so y = L^-1 (vals - mean) is ready when the last column is
+    // Blocked left-looking Cholesky for the EI path (many draws: every panel launch fills the chip).
+    // The log-likelihood path (a handful of draws) runs the same 64x64 tiles right-looking, on a
+    // tile-major copy of the matrix: one-step-deep launches instead of k sequential steps per tile, the
+    // diagonal block factored inside the update launch (k_lean_step); same accumulation order, same bits.
+    const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
+    TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, rl != 0));
+    // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
+    // so y = L^-1 (vals - mean) is ready when the last column is
     double* rhs = nullptr;
     if (lean) {
         if ((rc = h->rhs.reserve((size_t)nh * SPX_NB * Np * 8))) return rc;
         rhs = h->rhs.d();
-        TIMED(ST_GAMMA_ALPHA, launch_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh));
+        if (rl) {
+            if ((rc = h->diagL.reserve((size_t)nh * Np * 8))) return rc;
+            TIMED(ST_GAMMA_ALPHA, launch_lean_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh));
+        } else {
+            TIMED(ST_GAMMA_ALPHA, launch_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh));
+        }
+        h->lean_tiled = rl != 0;
     }
-    // Blocked left-looking Cholesky for the EI path (many draws: every panel launch fills the chip).
-    // The log-likelihood path (a handful of draws) runs the same tiles right-looking: one-step-deep
-    // launches instead of k sequential steps per tile, the diagonal block factored inside the update
-    // launch (k_lean_step); same accumulation order, same bits.
-    const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
     for (int k = 0; k < nblk; ++k) {
-        if (rl) TIMED(ST_CHOL_DIAG, launch_lean_step(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, Np, k, nh));
-        else TIMED(ST_CHOL_DIAG, launch_chol_diag(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, Np, k, nh, 0));
-        if (k + 1 < nblk || rhs) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh, rhs, rl));
+        if (rl) {
+            TIMED(ST_CHOL_DIAG, launch_lean_step(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), Np, k, nh));
+            TIMED(ST_CHOL_PANEL, launch_lean_trsm(s, h->Lm.d(), h->Dinv.d(), rhs, Np, k, nh));
+        } else {
+            TIMED(ST_CHOL_DIAG, launch_chol_diag(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, Np, k, nh, 0));
+            if (k + 1 < nblk || rhs) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh, rhs, 0));
+        }
     }
     if (!lean) {
         TIMED(ST_TRINV, launch_trinv(s, h->Lm.d(), h->Dinv.d(), h->WT.d(), Np, nh));
@@ -698,7 +709,10 @@ int spx_gp_logprob(spx_handle* h, double* out)
     int rc = do_factor(h, true, true);   // K(X,X), Cholesky, forward solve -- no inverse
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
-    launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);
+    if (h->lean_tiled)
+        launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, h->lp.d(), (int)h->N, h->Np, h->H);
+    else
+        launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);
     HIPCHK(hipMemcpyAsync(out, h->lp.p, (size_t)h->H * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SPX_OK;

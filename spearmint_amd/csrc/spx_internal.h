@@ -82,6 +82,8 @@ struct spx_handle {
     DevBuf rec_send, rec_recv, rec_out;   // {best mean EI, global index} records of the multi-GPU all-gather
     DevBuf sobol_dirs, sobol_out;                                   // spx_sobol_grid
     DevBuf rhs;                                                     // spx_gp_logprob: [H][64][Np] right-hand-side rows
+    DevBuf diagL;                                                   // spx_gp_logprob (tile-major path): diag(L), [H][Np]
+    bool lean_tiled = false;                                        // the last lean factorisation used tile-major storage
 
     double best_val = 0.0;
     int64_t best_idx = -1;
