@@ -533,9 +533,12 @@ void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double
 }
 
 // L_ik = A_ik L_kk^-T for the tiles below the diagonal block of column k and for the right-hand-side
-// rows (last workgroup): one MFMA tile product, in place.
-__global__ __launch_bounds__(256, 2) void k_lean_trsm(double* __restrict__ Lt, const double* __restrict__ Dinv,
-                                                   double* __restrict__ rhs, int Np, int k)
+// rows (last workgroup): one 64x64x64 tile product, in place.  This launch sits on the critical path of
+// every block column, so the product is spread over SIXTEEN wavefronts (1024 threads, a 16x16 output
+// block and 16 MFMAs each -- 0.4 us of matrix pipe instead of 1.7): waves 0-3 bring the tile in, waves
+// 4-7 the inverse of the diagonal block.
+__global__ __launch_bounds__(1024) void k_lean_trsm(double* __restrict__ Lt, const double* __restrict__ Dinv,
+                                                    double* __restrict__ rhs, int Np, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;              // [64][LDP]
@@ -548,15 +551,33 @@ __global__ __launch_bounds__(256, 2) void k_lean_trsm(double* __restrict__ Lt, c
     const int i = k + 1 + blockIdx.x;
     double* tile = is_rhs ? rhs + ((size_t)h * nblk + k) * LEAN_TILE
                           : Lt + (size_t)h * Np * Np + ((size_t)i * nblk + k) * LEAN_TILE;
-    d4 acc[4];
-    load_tile(tile, acc);
-    acc_tile_to_lds(acc, A, wave, g, li);
-    tile_to_lds(Dinv + ((size_t)h * nblk + k) * NB * NB, NB, B);
-    __syncthreads();
+    if (wave < 4) {
+        d4 t[4];
+        load_tile(tile, t);        // threadIdx.x < 256: the tile's own thread slots
+        acc_tile_to_lds(t, A, wave, g, li);
+    } else if (wave < 8) {
+        const double* Dk = Dinv + ((size_t)h * nblk + k) * NB * NB;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
-    mma_tile_64(A, B, acc, wave, g, li, false);
-    store_tile(tile, acc);
+        for (int q = 0; q < 8; ++q) {
+            const int idx = (threadIdx.x - 256) + 256 * q;  // double2 units
+            const int row = idx >> 5, c2 = idx & 31;
+            *reinterpret_cast<d2*>(B + row * LDP + 2 * c2) = *reinterpret_cast<const d2*>(Dk + (size_t)row * NB + 2 * c2);
+        }
+    }
+    __syncthreads();
+    // wave (wr, wc): out[16 wr + .][16 wc + .] = sum_q A[16 wr + .][q] Dinv[16 wc + .][q]
+    const int wr = wave >> 2, wc = wave & 3;
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        const double a = A[(16 * wr + li) * LDP + k0 + g];
+        const double bv = B[(16 * wc + li) * LDP + k0 + g];
+        acc = MFMA_F64(a, bv, acc);
+    }
+    // element (16 wr + g + 4 r, 16 wc + li) = value q = 4 wc + r of tile thread t = 64 wr + lane
+    d2* p = reinterpret_cast<d2*>(tile) + (64 * wr + lane);
+    p[(2 * wc) * 256] = (d2){acc[0], acc[1]};
+    p[(2 * wc + 1) * 256] = (d2){acc[2], acc[3]};
 }
 
 void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs, int Np, int k, int nh)
@@ -565,7 +586,7 @@ void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs
     const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);   // 67.6 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_trsm),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_lean_trsm, dim3(nrows + 1, nh), dim3(256), lds, s, Lt, Dinv, rhs, Np, k);
+    hipLaunchKernelGGL(k_lean_trsm, dim3(nrows + 1, nh), dim3(1024), lds, s, Lt, Dinv, rhs, Np, k);
 }
 
 // the right-hand-side block row in tile storage: row 0 = vals - mean (0 for pad entries), rows 1..63 = 0
