@@ -18,4 +18,4 @@ pr = cProfile.Profile()
 t = time.time(); pr.enable()
 job = ch.next(grid, values, durations, candidates, pending, complete)
 pr.disable(); print("next() %.2f s" % (time.time() - t))
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats(os.environ.get("SPX_PROF_SORT", "cumulative")).print_stats(22)
