@@ -23,7 +23,7 @@ int main()
     double *dA, *dL, *dD; int* dI; long long* dS;
     hipMalloc(&dA, 32768); hipMalloc(&dL, 32768); hipMalloc(&dD, 32768); hipMalloc(&dI, 4); hipMalloc(&dS, 21 * 8);
     hipMemcpy(dA, A.data(), 32768, hipMemcpyHostToDevice); hipMemset(dI, 0, 4);
-    size_t lds = (2 * NB * LDP + 4 * 16 * 18) * sizeof(double);
+    size_t lds = (2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);
     hipFuncSetAttribute(reinterpret_cast<const void*>(bench), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(bench, dim3(1), dim3(256), lds, 0, dA, dL, dD, dI, dS);
     hipDeviceSynchronize();

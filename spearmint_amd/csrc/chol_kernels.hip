@@ -97,6 +97,10 @@ __device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B
 // k_chol_diag's 30 us: 8.5k cycles per 16x16 block).
 // Out: U[r] = (L^T)[q + 4r][c] (upper, zeros below the diagonal), X = L^-1 (lower).
 // Rows and columns < j of C are dead after their pivot (they collect garbage; nothing reads them).
+// (Splitting the two MFMAs over two wavefronts -- the factor wave publishing l and rinv through an LDS
+// mailbox, per pivot or per four pivots, the inverse wave spinning on a sequence word -- was measured:
+// the factor wave alone runs 300 cycles per pivot next to its busy neighbours, and the inverse wave
+// trails by ~1.1k cycles, 5.9k per sub-block either way against 5.85k for this single-wave form.)
 __device__ __forceinline__ void factor16_mfma(d4& C, d4& X, d4& U, int lane, int& bad, int pivot_base)
 {
     const int c = lane & 15, q = lane >> 4;
@@ -138,15 +142,20 @@ __device__ __forceinline__ void factor16_mfma(d4& C, d4& X, d4& U, int lane, int
 //   S   [64][LDP]  in: the updated diagonal block; out: L_kk in the lower triangle
 //   XT  [64][LDP]  out: (L_kk^-1)^T
 //   T16 [4][16][18] scratch: inverses of the 16x16 diagonal sub-blocks
-// then write L_kk (upper part zero) to Lkk (row stride ldl) and L_kk^-1 to Dk ([64][64]).
-// Blocked with 16x16 sub-blocks.  Per sub-block column b: (a) one wavefront factors and inverts the
-// diagonal sub-block on the matrix pipe (factor16_mfma); meanwhile the other three build the
-// off-diagonal blocks of row b-1 of the inverse, which only need what round b-1 finished; (b) the
-// sub-panel below is multiplied by the sub-block's inverse (MFMA); (c) the trailing sub-blocks get
-// their rank-16 update (MFMA).  Inverse by block forward substitution:
+// then write L_kk (upper part zero) to Lkk (row stride ldl; may be null) and L_kk^-1 to Dk ([64][64]).
+// Blocked with 16x16 sub-blocks b = 0..3; per round b
+//   phase 1  wave 0 factors and inverts sub-block (b,b) on the matrix pipe (factor16_mfma); waves 1-3
+//            finish the trailing updates of round b-1 -- every tile but (b,b), which wave 0 took
+//            itself -- and the off-diagonal blocks of row b-1 of the inverse
+//   phase 2  sub-panel: P_ti = S(ti,b) Linv_b^T for the tiles below (MFMA), wave 0 the first one
+//   phase 3  wave 0 alone: S(b+1,b+1) -= P_{b+1} P_{b+1}^T, the one tile its next factorisation needs
+// so the critical wave goes factor -> sub-panel tile -> trailing tile -> factor with two barriers per
+// round.  Inverse by block forward substitution:
 //   X_jj = Linv16_j ;  X_ij = -Linv16_i * sum_{p=j}^{i-1} L_ip X_pj          (i > j)
 // XT holds X transposed so that X_pj is read in the MFMA B-operand pattern; the accumulator of the
 // first product is itself in B-operand layout for the second.
+#define DIAG_T16_DOUBLES (4 * 16 * 18)
+
 __device__ __forceinline__ void inv_block_row(const double* S, double* XT, const double* T16, int i, int j,
                                               int g, int li)
 {
@@ -167,6 +176,22 @@ __device__ __forceinline__ void inv_block_row(const double* S, double* XT, const
     for (int r = 0; r < 4; ++r) XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
 }
 
+// S(ti,tj) -= P_ti P_tj^T with the sub-panel tiles of column b
+__device__ __forceinline__ void trail_tile(double* S, int ti, int tj, int b0, int g, int li)
+{
+    d4 c4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c4[r] = S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const double av = -S[(16 * ti + li) * LDP + b0 + 4 * ks + g];
+        const double bv = S[(16 * tj + li) * LDP + b0 + 4 * ks + g];
+        c4 = MFMA_F64(av, bv, c4);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li] = c4[r];
+}
+
 #ifdef SPX_DIAG_STAMPS   // dev: phase time stamps for scripts/ubench_diag.hip
 __shared__ long long g_stamp[32];
 #define STAMP(i) do { if (threadIdx.x == 0) g_stamp[i] = clock64(); } while (0)
@@ -177,13 +202,14 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                                            double* __restrict__ Lkk, size_t ldl, double* __restrict__ Dk,
                                            double* __restrict__ diag_out = nullptr)
 {
-    STAMP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     int bad = 0;
+    STAMP(0);
     for (int b = 0; b < 4; ++b) {
         const int b0 = 16 * b;
         double* Tb = T16 + b * 16 * 18;
+        // ---- phase 1 ----
         if (wave == 0) {
             d4 C, X, U;
 #pragma unroll
@@ -196,13 +222,21 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                 Tb[row * 18 + li] = X[r];                       // Linv16[row][col = li]
                 XT[(b0 + li) * LDP + b0 + row] = X[r];          // XT[col][row] = X[row][col]
             }
-        } else if (wave < b) {
-            inv_block_row(S, XT, T16, b - 1, wave - 1, g, li);   // row b-1 of the inverse, block column wave-1
+        } else if (b > 0) {
+            // trailing tiles of round b-1 other than (b,b): (ti,tj), b-1 < tj <= ti, dealt to waves 1-3
+            int idx = 0;
+            for (int ti = b; ti < 4; ++ti)
+                for (int tj = b; tj <= ti; ++tj) {
+                    if (ti == b && tj == b) continue;
+                    if ((idx++ % 3) == wave - 1) trail_tile(S, ti, tj, b0 - 16, g, li);
+                }
+            // row b-1 of the inverse: blocks j = 0 .. b-2
+            for (int j = wave - 1; j < b - 1; j += 3) inv_block_row(S, XT, T16, b - 1, j, g, li);
         }
         STAMP(1 + 4 * b);
         __syncthreads();
         STAMP(2 + 4 * b);
-        // (b) sub-panel: rows of tile ti = b+1+wave, P <- P Linv16^T
+        // ---- phase 2: sub-panel, rows of tile ti = b+1+wave: P <- P Linv16^T ----
         {
             const int ti = b + 1 + wave;
             if (ti < 4) {
@@ -217,34 +251,17 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                 for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + b0 + li] = c4[r];
             }
         }
-        __syncthreads();
+        if (b < 3) __syncthreads();   // round 3 has no sub-panel: nothing was written
         STAMP(3 + 4 * b);
-        // (c) trailing update of the sub-blocks (ti, tj), b < tj <= ti
-        {
-            int idx = 0;
-            for (int ti = b + 1; ti < 4; ++ti)
-                for (int tj = b + 1; tj <= ti; ++tj, ++idx) {
-                    if ((idx & 3) != wave) continue;
-                    d4 c4;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) c4[r] = S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const double av = -S[(16 * ti + li) * LDP + b0 + 4 * ks + g];
-                        const double bv = S[(16 * tj + li) * LDP + b0 + 4 * ks + g];
-                        c4 = MFMA_F64(av, bv, c4);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li] = c4[r];
-                }
-        }
-        if (b < 3) __syncthreads();   // round 3 has no sub-panel / trailing work: nothing was written
+        // ---- phase 3: the one trailing tile the next factorisation needs (its operands are wave 0's own) ----
+        if (wave == 0 && b < 3) trail_tile(S, b + 1, b + 1, b0, g, li);
         STAMP(4 + 4 * b);
     }
     if (wave == 0 && lane == 0 && bad) {
         if (*info_h == 0) *info_h = bad;
     }
-    if (wave < 3) inv_block_row(S, XT, T16, 3, wave, g, li);   // last row of the inverse
+    // last row of the inverse (row 2 is complete: its two blocks were built in phase 1 of round 3)
+    if (wave < 3) inv_block_row(S, XT, T16, 3, wave, g, li);
     __syncthreads();
     STAMP(17);
     // write L_kk (upper part zero) and its inverse, 16 bytes per lane; the log-likelihood path only
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
 
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh, int updated)
 {
-    const size_t lds = (size_t)(3 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 110 KB > the 64 KB default
+    const size_t lds = (size_t)(3 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 112 KB > the 64 KB default
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k, updated);
@@ -525,7 +542,7 @@ void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double
 {
     const int n = Np / NB - k;
     if (n <= 0) return;
-    const size_t lds = (size_t)(2 * NB * LDP + 4 * 16 * 18) * sizeof(double);   // 72 KB: two workgroups per CU
+    const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid = (k == 0) ? dim3(1, 1, nh) : dim3(n + (rhs ? 1 : 0), (n + LEAN_CH - 1) / LEAN_CH, nh);
