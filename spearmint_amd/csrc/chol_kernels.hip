@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             acc[nt][r] = Ar[(size_t)(16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li];
-    if (nsteps > 0) {   // = k (left-looking); 0 when the tile arrives fully updated (right-looking)
+    if (nsteps > 0) {   // the k steps of this tile's left-looking update
         TileRegs ta, tb;
         tile_load(Ar, Np, ta);
         tile_load(Lh + kb0 * Np, Np, tb);
@@ -411,20 +411,19 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* __restrict__ Lm,
             Ar[(size_t)(16 * wave + g + 4 * r) * Np + kb0 + 16 * nt + li] = acc[nt][r];
 }
 
-void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs,
-                       int right_looking)
+void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs)
 {
     const int nblk = Np / NB;
     const int nrows = nblk - k - 1;
-    // k = 0: the next diagonal block has no earlier steps; right-looking: nothing is deferred
-    const int pre = (k > 0 && nrows > 0 && !right_looking) ? 1 : 0;
+    // k = 0: the next diagonal block has no earlier steps
+    const int pre = (k > 0 && nrows > 0) ? 1 : 0;
     const int nx = nrows + pre + (rhs ? 1 : 0);
     if (nx <= 0) return;
     const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);                // 135 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_panel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chol_panel, dim3(nx, nh), dim3(256), lds, s, L, Dinv, Np, k, pre, rhs,
-                       right_looking ? 0 : k);
+                       k);
 }
 
 // ---------------------------------------------------------------------------

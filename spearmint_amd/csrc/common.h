@@ -40,8 +40,7 @@ void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const 
 
 // chol_kernels.hip
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh, int updated = 0);
-void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs = nullptr,
-                       int right_looking = 0);
+void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs = nullptr);
 // log-likelihood path, tile-major storage (chol_kernels.hip)
 void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int Np, int k,
                       int nh);

@@ -322,7 +322,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
             TIMED(ST_CHOL_PANEL, launch_lean_trsm(s, h->Lm.d(), h->Dinv.d(), rhs, Np, k, nh));
         } else {
             TIMED(ST_CHOL_DIAG, launch_chol_diag(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, Np, k, nh, 0));
-            if (k + 1 < nblk || rhs) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh, rhs, 0));
+            if (k + 1 < nblk || rhs) TIMED(ST_CHOL_PANEL, launch_chol_panel(s, h->Lm.d(), h->Dinv.d(), Np, k, nh, rhs));
         }
     }
     if (!lean) {
