@@ -450,7 +450,9 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 // in flight while the current one computes.  The steps reach each tile in the order p = 0, 1, ... as
 // in the left-looking kernel of the EI path, so the factor is bit-identical.
 // Grid (rows, column chunks, draws) over the trailing tiles; k = 0: only the diagonal workgroup.
+#ifndef LEAN_CH
 #define LEAN_CH 4
+#endif
 #define LEAN_TILE (NB * NB)
 
 // a tile in accumulator order <-> the [64][LDP] MFMA operand layout in LDS
