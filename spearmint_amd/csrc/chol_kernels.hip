@@ -449,7 +449,7 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 // tiles of one block row: the row operand stays in LDS, the next tile's operand and accumulator are
 // in flight while the current one computes.  The steps reach each tile in the order p = 0, 1, ... as
 // in the left-looking kernel of the EI path, so the factor is bit-identical.
-// Grid (rows, column chunks, draws) over the trailing tiles; k = 0: only the diagonal workgroup.
+// Grid (draws, rows, column chunks) over the trailing tiles; k = 0: only the diagonal workgroups.
 #ifndef LEAN_CH
 #define LEAN_CH 4
 #endif
@@ -492,12 +492,16 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, d
     double* T16 = B + NB * LDP;    // [4][16][18]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.z;
+    // Workgroups are dispatched in linear block order, x fastest: with the draws on x, the diagonal
+    // workgroups of ALL draws (row 0, chunk 0) start first and the bulk of the update fills in behind
+    // them; with the draws on z the last draw's diagonal block started only after the other draws'
+    // tiles had been handed out and stuck out at the end of the launch.
+    const int h = blockIdx.x;
     const int nblk = Np / NB;
-    const bool is_rhs = rhs && blockIdx.x == gridDim.x - 1;
-    const int i = k + blockIdx.x;
+    const bool is_rhs = rhs && blockIdx.y == gridDim.y - 1;
+    const int i = k + blockIdx.y;
     // this workgroup's tiles: block row i (or the right-hand-side rows), block columns j0 .. j1 - 1
-    const int j0 = k + blockIdx.y * LEAN_CH;
+    const int j0 = k + blockIdx.z * LEAN_CH;
     const int j1 = min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
     if (j0 >= j1) return;
     double* Lh = Lt + (size_t)h * Np * Np;
@@ -546,7 +550,7 @@ void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double
     const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const dim3 grid = (k == 0) ? dim3(1, 1, nh) : dim3(n + (rhs ? 1 : 0), (n + LEAN_CH - 1) / LEAN_CH, nh);
+    const dim3 grid = (k == 0) ? dim3(nh, 1, 1) : dim3(nh, n + (rhs ? 1 : 0), (n + LEAN_CH - 1) / LEAN_CH);
     hipLaunchKernelGGL(k_lean_step, grid, dim3(256), lds, s, Lt, Dinv, info, (k == 0) ? nullptr : rhs, diagL, Np, k);
 }
 
