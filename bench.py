@@ -290,6 +290,25 @@ def main():
     if args.gemm_waves:
         eng.set_option("gemm_waves", args.gemm_waves)
 
+    # The collective: by default the 16-byte records travel through torch.distributed (backend nccl = RCCL);
+    # SPX_BENCH_COLLECTIVE=lib attaches an RCCL communicator to the library handle instead (spx_comm_attach),
+    # so that spx_ei_run itself ends with the ncclAllGather and best() is already the global winner.
+    lib_collective = os.environ.get("SPX_BENCH_COLLECTIVE", "torch") == "lib"
+
+    def attach(e):
+        if not lib_collective:
+            return
+        if world == 1:
+            e.comm_attach(e.comm_unique_id(), 1, 0)
+            return
+        buf = torch.zeros(128, dtype=torch.uint8, device=tdev if tdev is not None else "cpu")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(e.comm_unique_id()), dtype=torch.uint8))
+        tdist.broadcast(buf, src=0)
+        e.comm_attach(bytes(buf.cpu().numpy().tobytes()), world, rank)
+
+    attach(eng)
+
     def run_steps(e, fl, nsteps):
         """nsteps timed steps bracketed by barrier + device sync; MAX over ranks."""
         out = None
@@ -299,7 +318,7 @@ def main():
             e.factor()
             e.ei_run(fl)
             idx, val = e.best()
-            out = spx_dist.exchange_best(val, idx, device=tdev)
+            out = (idx, val) if lib_collective else spx_dist.exchange_best(val, idx, device=tdev)
         sync()
         return max_over_ranks(time.perf_counter() - t0), out
 
@@ -364,7 +383,9 @@ def main():
             "config": {"workload": w["desc"], "N_obs": N, "candidates_per_gpu": M, "D": D,
                        "mcmc_iters": H, "per_sec": w["per_sec"],
                        "sharding": "candidates sharded contiguously over ranks, draws replicated; "
-                                   "one collective of (best EI, index) records"},
+                                   "one collective of (best EI, index) records",
+                       "collective": "libspx ncclAllGather (spx_comm_attach)" if lib_collective
+                                     else "torch.distributed all_gather_into_tensor"},
             "roofline": roofline, "roofline_hbm": roofline_hbm,
             "ms_per_step_with_events": dt_ev / ev_steps * 1e3,
             "stages_ms_per_step": {k: v[0] / ev_steps for k, v in tm.items() if v[1]},
@@ -401,6 +422,7 @@ def main():
             e2.set_hypers(shyp)
             if cfg["per_sec"]:
                 e2.set_time_model(sprob[4], sprob[5])
+            attach(e2)
             fl = FLAG_PER_SEC if cfg["per_sec"] else 0
             run_steps(e2, fl, 1)
             sdt, sbest = run_steps(e2, fl, args.extra_steps)

@@ -75,6 +75,16 @@ int  spx_create_multi(const int* device_ids, int32_t n_dev, spx_handle** out);
 #define SPX_TRANSPORT_HOST 2   /* records staged through host memory               */
 /* n_dev, transport and (up to cap) device ids of a handle; any pointer may be NULL */
 int  spx_multi_query(spx_handle* h, int32_t* n_dev, int32_t* transport, int32_t* device_ids, int32_t cap);
+/* One process per GPU (a launcher-based run, bench.py --gpus N): attach an RCCL communicator to a
+ * single-GPU handle.  Rank 0 obtains an id (ncclGetUniqueId), the launcher's own channel carries its
+ * SPX_COMM_ID_BYTES bytes to the other ranks, every rank attaches (ncclCommInitRank).  From then on
+ * spx_ei_run ends with the path's collective -- one ncclAllGather of the ranks' 16-byte {best mean EI,
+ * global index} records on the handle's stream and the same numpy-argmax reduction on every rank -- and
+ * spx_get_best returns the global winner.  Candidates are sharded by the caller (spx_set_candidates'
+ * index_base).                                                                                     */
+#define SPX_COMM_ID_BYTES 128
+int  spx_comm_unique_id(char* id_out /* SPX_COMM_ID_BYTES */);
+int  spx_comm_attach(spx_handle* h, const char* id, int32_t nranks, int32_t rank);
 void spx_destroy(spx_handle* h);
 const char* spx_last_error(void);
 int  spx_version(void);

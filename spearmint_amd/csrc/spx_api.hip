@@ -121,6 +121,7 @@ void spx_destroy(spx_handle* h)
 {
     if (!h) return;
     if (h->multi) { spx_multi_destroy(h->multi); delete h; return; }
+    spx_comm_release(h);
     if (h->inited) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
@@ -578,6 +579,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
     }
     h->ran = true;
     h->ran_moments = keep_mom && S == 0;
+    if (h->comm) return spx_comm_exchange(h);   // one process per GPU: the winner over all ranks
     return SPX_OK;
 }
 

@@ -66,6 +66,7 @@ struct spx_handle {
     int nstreams = 1;
     int gemm_variant = 0;               // predict-GEMM variant of THIS handle (option "gemm_waves"); 0 = production
     struct spx_multi* multi = nullptr;  // non-null: this handle fronts several per-GPU handles (spx_multi.hip)
+    struct spx_comm* comm = nullptr;    // non-null: one-process-per-GPU communicator attached (spx_comm_attach)
 
     std::vector<double> hyp_host, thyp_host;
 
@@ -123,5 +124,8 @@ int spx_multi_sobol_grid(spx_multi* m, const uint32_t* dirs, int32_t dim_max, in
 int spx_multi_not_pd_info(spx_multi* m, int32_t* draw, int32_t* pivot);
 int spx_multi_get_timings(spx_multi* m, double* ms, int64_t* launches, int n);
 int spx_multi_info(spx_multi* m, int32_t* n_dev, int32_t* transport, int32_t* device_ids, int32_t cap);
+// one process per GPU (spx_comm_attach): exchange this handle's record with the other ranks / drop the communicator
+int spx_comm_exchange(spx_handle* h);
+void spx_comm_release(spx_handle* h);
 // single-GPU pieces the multi layer needs
 int spx_ensure_init(spx_handle* h);

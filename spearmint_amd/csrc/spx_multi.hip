@@ -34,6 +34,8 @@
 struct RcclApi {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -56,12 +58,14 @@ static int load_rccl(RcclApi* r)
         RcclApi a;
         a.lib = lib;
         *(void**)&a.CommInitAll = dlsym(lib, "ncclCommInitAll");
+        *(void**)&a.GetUniqueId = dlsym(lib, "ncclGetUniqueId");
+        *(void**)&a.CommInitRank = dlsym(lib, "ncclCommInitRank");
         *(void**)&a.CommDestroy = dlsym(lib, "ncclCommDestroy");
         *(void**)&a.AllGather = dlsym(lib, "ncclAllGather");
         *(void**)&a.GroupStart = dlsym(lib, "ncclGroupStart");
         *(void**)&a.GroupEnd = dlsym(lib, "ncclGroupEnd");
         *(void**)&a.GetErrorString = dlsym(lib, "ncclGetErrorString");
-        if (!a.CommInitAll || !a.CommDestroy || !a.AllGather || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
+        if (!a.CommInitAll || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
             dlclose(lib);
             return fail(SPX_ERR_HIP, "spx_create_multi: librccl lacks an expected symbol");
         }
@@ -289,6 +293,47 @@ static int sync_hypers(spx_multi* m)
     return rc;
 }
 
+// ---- one process per GPU: a communicator attached to a single-GPU handle -------------------------------
+// spx_comm_attach makes spx_ei_run end with the same exchange as the multi-device handle, across
+// processes: k_make_record -> ONE ncclAllGather of the 16-byte records on the handle's stream ->
+// k_pick_record; spx_get_best then returns the global winner on every rank.
+struct spx_comm {
+    RcclApi rccl;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+int spx_comm_exchange(spx_handle* k)
+{
+    spx_comm* c = k->comm;
+    int rc = spx_ensure_init(k);
+    if (rc) return rc;
+    if ((rc = k->rec_send.reserve(sizeof(SpxRecord)))) return rc;
+    if ((rc = k->rec_recv.reserve(sizeof(SpxRecord) * c->nranks))) return rc;
+    if ((rc = k->rec_out.reserve(sizeof(SpxRecord)))) return rc;
+    hipLaunchKernelGGL(k_make_record, dim3(1), dim3(1), 0, k->stream, (const double*)k->am_out_val.p,
+                       (const int64_t*)k->am_out_idx.p, k->index_base, 1, (SpxRecord*)k->rec_send.p);
+    ncclResult_t r = c->rccl.AllGather(k->rec_send.p, k->rec_recv.p, sizeof(SpxRecord), ncclChar, c->comm, k->stream);
+    if (r != ncclSuccess) return fail(SPX_ERR_HIP, "ncclAllGather failed: %s", c->rccl.GetErrorString(r));
+    hipLaunchKernelGGL(k_pick_record, dim3(1), dim3(1), 0, k->stream, (const SpxRecord*)k->rec_recv.p, c->nranks,
+                       (SpxRecord*)k->rec_out.p);
+    SpxRecord out;
+    HIPCHK(hipMemcpyAsync(&out, k->rec_out.p, sizeof out, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(hipStreamSynchronize(k->stream));
+    HIPCHK(hipGetLastError());
+    k->best_idx = out.idx - k->index_base;   // spx_get_best adds the base back
+    k->best_val = out.val;
+    return SPX_OK;
+}
+
+void spx_comm_release(spx_handle* k)
+{
+    if (!k->comm) return;
+    if (k->comm->comm) (void)k->comm->rccl.CommDestroy(k->comm->comm);
+    delete k->comm;
+    k->comm = nullptr;
+}
+
 extern "C" {
 
 int spx_create_multi(const int* device_ids, int32_t n_dev, spx_handle** out)
@@ -343,6 +388,45 @@ int spx_multi_query(spx_handle* h, int32_t* n_dev, int32_t* transport, int32_t* 
         return SPX_OK;
     }
     return spx_multi_info(h->multi, n_dev, transport, device_ids, cap);
+}
+
+int spx_comm_unique_id(char* id_out)
+{
+    if (!id_out) return fail(SPX_ERR_ARG, "spx_comm_unique_id: null");
+    RcclApi api;
+    int rc = load_rccl(&api);
+    if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t r = api.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(SPX_ERR_HIP, "ncclGetUniqueId failed: %s", api.GetErrorString(r));
+    static_assert(sizeof(ncclUniqueId) == SPX_COMM_ID_BYTES, "unique id size");
+    memcpy(id_out, &id, sizeof id);
+    return SPX_OK;
+}
+
+int spx_comm_attach(spx_handle* h, const char* id, int32_t nranks, int32_t rank)
+{
+    if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(SPX_ERR_ARG, "spx_comm_attach: bad arguments (nranks=%d, rank=%d)", nranks, rank);
+    if (h->multi) return fail(SPX_ERR_ARG, "spx_comm_attach: a multi-device handle has its own communicator");
+    int rc = spx_ensure_init(h);   // hipSetDevice(h->device): the communicator binds to the current device
+    if (rc) return rc;
+    spx_comm_release(h);
+    spx_comm* c = new spx_comm();
+    if ((rc = load_rccl(&c->rccl))) { delete c; return rc; }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = c->rccl.CommInitRank(&c->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        rc = fail(SPX_ERR_HIP, "ncclCommInitRank(%d of %d) failed: %s", rank, nranks, c->rccl.GetErrorString(r));
+        delete c;
+        return rc;
+    }
+    c->nranks = nranks;
+    c->rank = rank;
+    h->comm = c;
+    h->ran = false;
+    return SPX_OK;
 }
 
 }  // extern "C"

@@ -36,6 +36,8 @@ ABI = {
     "spx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "spx_create_multi": (ctypes.c_int, [_c_int32_p, ctypes.c_int32, ctypes.POINTER(_vp)]),
     "spx_multi_query": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p, _c_int32_p, ctypes.c_int32]),
+    "spx_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "spx_comm_attach": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]),
     "spx_destroy": (None, [_vp]),
     "spx_last_error": (ctypes.c_char_p, []),
     "spx_version": (ctypes.c_int, []),
@@ -146,6 +148,19 @@ class Engine(object):
             self.device = int(device)
             self.devices = [self.device]
         self.N = self.M = self.D = self.H = 0
+
+    def comm_unique_id(self):
+        """128 bytes identifying a new RCCL communicator (call on one rank, ship to the others)."""
+        buf = ctypes.create_string_buffer(128)
+        self._check(self._lib.spx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_attach(self, uid, nranks, rank):
+        """One process per GPU: join the communicator `uid`; every later ei_run ends with the library's own
+        ncclAllGather of the ranks' {best EI, index} records and best() returns the global winner."""
+        if len(uid) != 128:
+            raise ValueError("uid must be the 128 bytes of comm_unique_id()")
+        self._check(self._lib.spx_comm_attach(self._h, uid, int(nranks), int(rank)))
 
     def transport(self):
         """"none" (one GPU), "rccl" (ncclAllGather over the devices) or "host" (repeated device

@@ -301,3 +301,40 @@ def test_bench_in_process_mode_matches_the_default_mode(eng):
     s1 = bench.weak_problem(w, 1)[4]
     idx, val, _, _ = eng.ei_grid(comp, vals, np.vstack((s0, s1)), hypers)
     assert out["config"]["transport"] == "host" and (out["best_index"], out["best_ei"]) == (idx, val)
+
+
+@pytest.mark.timeout(300)
+def test_process_group_communicator_attached_to_a_handle(eng):
+    """spx_comm_attach: the one-process-per-GPU form of the library's collective (here a group of one rank):
+    ei_run ends with ncclAllGather + the argmax rule, best() is the global winner."""
+    comp, cand, vals, hypers = synthetic_problem(150, 2500, 5, 4, 91)
+    ref = eng.ei_grid(comp, vals, cand, hypers)
+    e = Engine(0)
+    try:
+        uid = e.comm_unique_id()
+        assert len(uid) == 128
+        e.comm_attach(uid, 1, 0)
+        e.set_observations(comp, vals); e.set_hypers(hypers); e.factor()
+        e.set_candidates(cand[1000:], index_base=1000)          # a shard with a global offset
+        e.ei_run()
+        sub = eng.ei_grid(comp, vals, cand[1000:], hypers)
+        assert e.best() == (sub[0] + 1000, sub[1])
+        e.set_candidates(cand)
+        e.ei_run()
+        assert e.best() == (ref[0], ref[1])
+        with pytest.raises(ValueError):
+            e.comm_attach(uid[:10], 1, 0)
+    finally:
+        e.close()
+    # bench.py with the library collective (one rank)
+    env = dict(os.environ, SPX_BENCH_COLLECTIVE="lib")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "c2",
+           "--no-cpu-baseline", "--skip-extras"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert "ncclAllGather" in out["config"]["collective"]
+    w = bench.WORKLOADS["c2"]
+    _, c2, v2, h2, s0 = bench.weak_problem(w, 0)
+    idx, val, _, _ = eng.ei_grid(c2, v2, s0, h2)
+    assert (out["best_index"], out["best_ei"]) == (idx, val)
