@@ -24,6 +24,7 @@ Fixtures (all float64, ref = the reference's own functions):
                    (seeded; burnin + MCMC + refinement), the point they propose.
   chooser_next_pending.npz  the same with three pending jobs (fantasy branch).
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
+  chooser_next_noiseless.npz  seeded next() of the three choosers with noiseless=1.
   chooser_next_ml2.npz  GPEIChooser.next with mcmc_iters=0 (ML-II hypers, gp.py:181-292).
   ei_grad.npz      the refinement objective: GPEIOptChooser.grad_optimize_ei_over_hypers
                    without and with pending jobs, GPEIperSecChooser.grad_optimize_ei_over_hypers
@@ -329,6 +330,34 @@ def gen_ml2(mods, tmp):
                         hyper=np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)))
 
 
+def gen_noiseless(mods, tmp):
+    """noiseless=1 (noise pinned to 1e-3, the joint slice move over [mean, amp2] only:
+    GPEIChooser.py:268-270, :316-346; GPEIOptChooser.py:621-626, :672-706): seeded next() of the three choosers."""
+    grid, values, durations, cand, pend, comp = _branin_inputs(mods, 12, 300)
+    out = {}
+    specs = (("g", "GPEIChooser", dict(mcmc_iters=3, noiseless=1), 1000),
+             ("o", "GPEIOptChooser", dict(mcmc_iters=3, burnin=4, grid_subset=3, noiseless=1, use_multiprocessing=0), 1100),
+             ("p", "GPEIperSecChooser", dict(mcmc_iters=2, burnin=3, grid_subset=3, noiseless=1), 1200))
+    for tag, name, kw, seed0 in specs:
+        for seed in range(seed0, seed0 + 40):
+            ch = getattr(mods[name], name)(tempfile.mkdtemp(prefix="spx_golden_nl_"), **kw)
+            npr.seed(seed)
+            try:
+                job = ch.next(grid, values, durations, cand, pend, comp)
+            except Exception as e:
+                print("noiseless", name, "seed", seed, "reference raised:", e)
+                if name == "GPEIChooser":
+                    ch.ls = np.ones(2); ch.amp2 = ch.noise = ch.mean = 0.0
+                continue
+            out.update({tag + "_seed": seed, tag + "_is_new": int(isinstance(job, tuple)),
+                        tag + "_index": int(job[0] if isinstance(job, tuple) else job),
+                        tag + "_point": np.asarray(job[1] if isinstance(job, tuple) else grid[job]),
+                        tag + "_hyper": np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls))})
+            break
+    np.savez_compressed(os.path.join(OUT, "chooser_next_noiseless.npz"), grid=grid, values=values,
+                        durations=durations, candidates=cand, pending=pend, complete=comp, **out)
+
+
 def gen_ei_grad(mods, tmp):
     """The L-BFGS-B objective of the local refinement, evaluated by the reference itself
     (GPEIOptChooser.py:360-525, GPEIperSecChooser.py:322-434)."""
@@ -388,7 +417,7 @@ def gen_ei_grad(mods, tmp):
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 

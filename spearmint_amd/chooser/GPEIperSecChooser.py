@@ -101,6 +101,12 @@ class GPEIperSecChooser(GPEIBase):
     # -- the hot path ----------------------------------------------------------------
     def ei_per_s_over_hypers_gpu(self, comp, pend, cand, vals, durs):
         rows, trows = self._paired_samples()
+        if self.ref_compat:
+            # a consequence of defect (i): ei_over_hypers leaves the chooser's CURRENT hypers at the one
+            # pair it evaluated (:288-296), so that is what dump_hypers pickles and where the next call's
+            # chain starts
+            self.mean, self.noise, self.amp2, self.ls = self.hyper_samples[0]
+            self.time_mean, self.time_noise, self.time_amp2, self.time_ls = self.time_hyper_samples[0]
         self._lp_key = None
         self._resident_plain = pend.shape[0] == 0   # the engine then holds exactly (comp, rows, trows)
         if pend.shape[0] > 0:

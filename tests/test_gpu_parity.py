@@ -465,3 +465,9 @@ def test_gpei_chooser_ml2_hypers_on_gpu(golden_dir, tmp_path):
     comp, cand = g["grid"][g["complete"]], g["grid"][g["candidates"]]
     ref = orc.ei_over_hypers(comp, cand, g["values"][g["complete"]], g["hyper"][None, :])
     assert_ei_close(ch.last_overall_ei, ref, rtol=1e-6)
+
+
+def test_noiseless_choosers_on_gpu_match_reference(golden_dir, tmp_path):
+    """The same three seeded noiseless=1 runs as tests/test_host_logic.py, on the real engine."""
+    from tests.test_host_logic import _noiseless_runs
+    _noiseless_runs(golden_dir, tmp_path, lambda: None)

@@ -320,3 +320,33 @@ def test_gpei_next_ml2_hypers_matches_reference(golden_dir, tmp_path):
         c2 = mod.init(str(tmp_path), "mcmc_iters=0"); c2._eng = OracleEngine()
         with pytest.raises(NotImplementedError):
             c2.next(g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+
+
+def _noiseless_runs(golden_dir, tmp_path, make_engine):
+    g = _g(golden_dir, "chooser_next_noiseless.npz")
+    args = (g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    specs = (("g", GPEIChooser, "mcmc_iters=3,noiseless=1"),
+             ("o", GPEIOptChooser, "mcmc_iters=3,burnin=4,grid_subset=3,noiseless=1,use_multiprocessing=0"),
+             ("p", GPEIperSecChooser, "mcmc_iters=2,burnin=3,grid_subset=3,noiseless=1,ref_compat=1"))
+    for tag, mod, arg in specs:
+        d = tmp_path / tag
+        d.mkdir()
+        ch = mod.init(str(d), arg)
+        eng = make_engine()
+        if eng is not None:
+            ch._eng = eng
+        npr.seed(int(g[tag + "_seed"]))
+        job = ch.next(*args)
+        assert ch.noise == 1e-3
+        assert np.allclose(np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)), g[tag + "_hyper"], rtol=1e-6)
+        if int(g[tag + "_is_new"]):
+            assert isinstance(job, tuple) and job[0] == int(g[tag + "_index"])
+            assert np.allclose(job[1], g[tag + "_point"], atol=1e-5)
+        else:
+            assert job == int(g[tag + "_index"])
+
+
+def test_noiseless_choosers_match_reference(golden_dir, tmp_path):
+    """noiseless=1: noise pinned to 1e-3, joint slice move over [mean, amp2] only (GPEIChooser.py:268-270,
+    :316-346): same hyper draws and proposals as the reference's own seeded runs."""
+    _noiseless_runs(golden_dir, tmp_path, OracleEngine)
