@@ -25,6 +25,7 @@ Fixtures (all float64, ref = the reference's own functions):
   chooser_next_pending.npz  the same with three pending jobs (fantasy branch).
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
   chooser_next_noiseless.npz  seeded next() of the three choosers with noiseless=1.
+  chooser_two_calls.npz  next(), restart from the state pickle with a new chooser object, next() again.
   chooser_next_ml2.npz  GPEIChooser.next with mcmc_iters=0 (ML-II hypers, gp.py:181-292).
   ei_grad.npz      the refinement objective: GPEIOptChooser.grad_optimize_ei_over_hypers
                    without and with pending jobs, GPEIperSecChooser.grad_optimize_ei_over_hypers
@@ -358,6 +359,44 @@ def gen_noiseless(mods, tmp):
                         durations=durations, candidates=cand, pending=pend, complete=comp, **out)
 
 
+def gen_two_calls(mods, tmp):
+    """Restart semantics (spearmint-lite builds a fresh chooser on every invocation): next() with 12 completed
+    jobs, the chooser dropped (its state pickled), a NEW chooser object in the same expt_dir, next() with 14."""
+    grid, values, durations, cand, pend, comp = _branin_inputs(mods, 14, 300)
+    first = (grid, np.where(np.arange(len(values)) < 12, values, np.nan), np.where(np.arange(len(values)) < 12, durations, np.nan),
+             np.arange(12, len(values)), pend, np.arange(12))
+    second = (grid, values, durations, cand, pend, comp)
+    out = {}
+    specs = (("g", "GPEIChooser", dict(mcmc_iters=3), 1300),
+             ("o", "GPEIOptChooser", dict(mcmc_iters=3, burnin=4, grid_subset=3, use_multiprocessing=0), 1400),
+             ("p", "GPEIperSecChooser", dict(mcmc_iters=2, burnin=3, grid_subset=3), 1500))
+    for tag, name, kw, seed0 in specs:
+        for seed in range(seed0, seed0 + 40):
+            d = tempfile.mkdtemp(prefix="spx_golden_2c_")
+            try:
+                ch = getattr(mods[name], name)(d, **kw)
+                npr.seed(seed)
+                job1 = ch.next(*first)
+                h1 = np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls))
+                if name == "GPEIChooser":
+                    ch.__del__()                 # what the interpreter does when the driver lets go of it
+                ch2 = getattr(mods[name], name)(d, **kw)
+                npr.seed(seed + 7)
+                job2 = ch2.next(*second)
+                h2 = np.concatenate(([ch2.mean, ch2.noise, ch2.amp2], ch2.ls))
+            except Exception as e:
+                print("two calls", name, "seed", seed, "reference raised:", e)
+                continue
+            def idx(j): return int(j[0] if isinstance(j, tuple) else j)
+            def pt(j): return np.asarray(j[1] if isinstance(j, tuple) else grid[j])
+            out.update({tag + "_seed": seed, tag + "_new1": int(isinstance(job1, tuple)), tag + "_idx1": idx(job1),
+                        tag + "_pt1": pt(job1), tag + "_h1": h1, tag + "_new2": int(isinstance(job2, tuple)),
+                        tag + "_idx2": idx(job2), tag + "_pt2": pt(job2), tag + "_h2": h2})
+            break
+    np.savez_compressed(os.path.join(OUT, "chooser_two_calls.npz"), grid=grid, values=values, durations=durations,
+                        candidates=cand, pending=pend, complete=comp, **out)
+
+
 def gen_ei_grad(mods, tmp):
     """The L-BFGS-B objective of the local refinement, evaluated by the reference itself
     (GPEIOptChooser.py:360-525, GPEIperSecChooser.py:322-434)."""
@@ -417,7 +456,7 @@ def gen_ei_grad(mods, tmp):
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless, gen_two_calls):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 

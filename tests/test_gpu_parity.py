@@ -471,3 +471,9 @@ def test_noiseless_choosers_on_gpu_match_reference(golden_dir, tmp_path):
     """The same three seeded noiseless=1 runs as tests/test_host_logic.py, on the real engine."""
     from tests.test_host_logic import _noiseless_runs
     _noiseless_runs(golden_dir, tmp_path, lambda: None)
+
+
+def test_restart_between_calls_on_gpu_matches_reference(golden_dir, tmp_path):
+    """next(), a new chooser object on the same expt_dir, next(): the reference's two proposals, on the real engine."""
+    from tests.test_host_logic import _two_call_runs
+    _two_call_runs(golden_dir, tmp_path, lambda: None)

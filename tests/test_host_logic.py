@@ -346,6 +346,51 @@ def _noiseless_runs(golden_dir, tmp_path, make_engine):
             assert job == int(g[tag + "_index"])
 
 
+def _two_call_runs(golden_dir, tmp_path, make_engine):
+    g = _g(golden_dir, "chooser_two_calls.npz")
+    values, durations = g["values"], g["durations"]
+    early = np.arange(len(values)) < 12
+    first = (g["grid"], np.where(early, values, np.nan), np.where(early, durations, np.nan),
+             np.arange(12, len(values)), g["pending"], np.arange(12))
+    second = (g["grid"], values, durations, g["candidates"], g["pending"], g["complete"])
+    specs = (("g", GPEIChooser, "mcmc_iters=3"),
+             ("o", GPEIOptChooser, "mcmc_iters=3,burnin=4,grid_subset=3,use_multiprocessing=0"),
+             ("p", GPEIperSecChooser, "mcmc_iters=2,burnin=3,grid_subset=3,ref_compat=1"))
+
+    def check(job, ch, k):
+        assert np.allclose(np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)), g["%s_h%d" % (tag, k)], rtol=1e-6)
+        if int(g["%s_new%d" % (tag, k)]):
+            assert isinstance(job, tuple) and job[0] == int(g["%s_idx%d" % (tag, k)])
+            assert np.allclose(job[1], g["%s_pt%d" % (tag, k)], atol=1e-5)
+        else:
+            assert job == int(g["%s_idx%d" % (tag, k)])
+
+    for tag, mod, arg in specs:
+        d = tmp_path / tag
+        d.mkdir()
+        ch = mod.init(str(d), arg)
+        eng = make_engine()
+        if eng is not None:
+            ch._eng = eng
+        seed = int(g[tag + "_seed"])
+        npr.seed(seed)
+        check(ch.next(*first), ch, 1)
+        if mod is GPEIChooser:
+            ch.__del__()
+        ch2 = mod.init(str(d), arg)
+        eng = make_engine()
+        if eng is not None:
+            ch2._eng = eng
+        npr.seed(seed + 7)
+        check(ch2.next(*second), ch2, 2)
+
+
+def test_restart_between_calls_matches_reference(golden_dir, tmp_path):
+    """spearmint-lite builds a fresh chooser per invocation: the second next() of a NEW object in the same
+    expt_dir starts from the pickled state (hypers, burn-in already done) exactly as the reference's does."""
+    _two_call_runs(golden_dir, tmp_path, OracleEngine)
+
+
 def test_noiseless_choosers_match_reference(golden_dir, tmp_path):
     """noiseless=1: noise pinned to 1e-3, joint slice move over [mean, amp2] only (GPEIChooser.py:268-270,
     :316-346): same hyper draws and proposals as the reference's own seeded runs."""
