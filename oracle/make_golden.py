@@ -25,6 +25,7 @@ Fixtures (all float64, ref = the reference's own functions):
   chooser_next_pending.npz  the same with three pending jobs (fantasy branch).
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
   chooser_next_noiseless.npz  seeded next() of the three choosers with noiseless=1.
+  branin_trajectory.npz  whole optimisation runs (24 / 14 proposals) of GPEIChooser / GPEIOptChooser on Branin.
   chooser_two_calls.npz  next(), restart from the state pickle with a new chooser object, next() again.
   chooser_next_ml2.npz  GPEIChooser.next with mcmc_iters=0 (ML-II hypers, gp.py:181-292).
   ei_grad.npz      the refinement objective: GPEIOptChooser.grad_optimize_ei_over_hypers
@@ -397,6 +398,56 @@ def gen_two_calls(mods, tmp):
                         candidates=cand, pending=pend, complete=comp, **out)
 
 
+def run_trajectory(make_chooser, grid, iters, seed, first=2):
+    """A whole optimisation run as spearmint-lite drives it (spearmint-lite.py:171-197 -- a fresh chooser per
+    invocation, restarting from its state pickle; one proposal per invocation; a proposed NEW point is appended
+    to the grid): returns the proposals [(is_new, index, point)] and the objective values."""
+    grid = np.array(grid, copy=True)
+    values = np.zeros(grid.shape[0]) + np.nan
+    durations = np.zeros(grid.shape[0]) + np.nan
+    done = np.zeros(grid.shape[0], dtype=bool)
+    out = []
+    for it in range(iters):
+        ch = make_chooser()
+        npr.seed(seed + it)
+        cand, comp = np.nonzero(~done)[0], np.nonzero(done)[0]
+        job = ch.next(grid, values, durations, cand, np.zeros(0, dtype=int), comp)
+        if isinstance(job, tuple):
+            idx, pt = int(job[0]), np.asarray(job[1], dtype=float).ravel()
+            grid = np.vstack((grid, pt[None, :]))
+            values, durations, done = np.append(values, np.nan), np.append(durations, np.nan), np.append(done, False)
+            idx = grid.shape[0] - 1
+            out.append((1, idx, pt))
+        else:
+            idx = int(job)
+            out.append((0, idx, grid[idx].copy()))
+        values[idx] = branin(grid[idx, 0], grid[idx, 1])
+        durations[idx] = 1.0 + 3.0 * grid[idx, 0] + np.sin(5 * grid[idx, 1]) ** 2
+        done[idx] = True
+        if type(ch).__name__ == "GPEIChooser" and hasattr(ch, "ls"):
+            ch.__del__()             # pickles the chain state; the interpreter calls it when the driver exits
+    return out, values[np.isfinite(values)], grid
+
+
+def gen_trajectory(mods, tmp):
+    """Whole Branin runs of the reference's choosers under a spearmint-lite-style loop: the sequence of
+    experiments a user would see (README.md:136-137 quotes the optimum 0.39 as the expected outcome)."""
+    sob = mods["sobol_lib"]
+    grid = np.transpose(sob.i4_sobol_generate(2, 400, 1))
+    out = {"grid": grid}
+    for tag, name, kw, iters, seed in (("g", "GPEIChooser", dict(mcmc_iters=4), 24, 7000),
+                                       ("o", "GPEIOptChooser", dict(mcmc_iters=3, burnin=5, grid_subset=4, use_multiprocessing=0), 14, 7100)):
+        d = tempfile.mkdtemp(prefix="spx_golden_traj_")
+        props, vals, _ = run_trajectory(lambda: getattr(mods[name], name)(d, **kw), grid, iters, seed)
+        out[tag + "_seed"], out[tag + "_iters"] = seed, iters
+        out[tag + "_new"] = np.array([p[0] for p in props])
+        out[tag + "_idx"] = np.array([p[1] for p in props])
+        out[tag + "_pts"] = np.array([p[2] for p in props])
+        out[tag + "_best"] = float(np.min([branin(p[2][0], p[2][1]) for p in props]))
+        print("trajectory", name, "best", out[tag + "_best"], "new points", int(out[tag + "_new"].sum()))
+    np.savez_compressed(os.path.join(OUT, "branin_trajectory.npz"), **out)
+
+
 def gen_ei_grad(mods, tmp):
     """The L-BFGS-B objective of the local refinement, evaluated by the reference itself
     (GPEIOptChooser.py:360-525, GPEIperSecChooser.py:322-434)."""
@@ -456,7 +507,7 @@ def gen_ei_grad(mods, tmp):
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless, gen_two_calls):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless, gen_two_calls, gen_trajectory):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 

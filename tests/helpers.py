@@ -135,3 +135,40 @@ def np_mean_device_order(row):
         return pw(a[:n2]) + pw(a[n2:])
     row = [np.float64(x) for x in row]
     return (np.float64(0.0) + pw(row)) / np.float64(len(row))
+
+
+def branin(x0, x1):
+    a = x0 * 15
+    b = (x1 * 15) - 5
+    return (np.square(b - (5.1 / (4 * np.square(np.pi))) * np.square(a) + (5 / np.pi) * a - 6)
+            + 10 * (1 - (1. / (8 * np.pi))) * np.cos(a) + 10)
+
+
+def run_trajectory(make_chooser, grid, iters, seed):
+    """The loop oracle/make_golden.py:run_trajectory drove the REFERENCE's choosers with (a fresh chooser per
+    proposal, restarted from its state pickle, new points appended to the grid), here for our choosers."""
+    import numpy.random as npr
+    grid = np.array(grid, copy=True)
+    values = np.zeros(grid.shape[0]) + np.nan
+    durations = np.zeros(grid.shape[0]) + np.nan
+    done = np.zeros(grid.shape[0], dtype=bool)
+    out = []
+    for it in range(iters):
+        ch = make_chooser()
+        npr.seed(seed + it)
+        job = ch.next(grid, values, durations, np.nonzero(~done)[0], np.zeros(0, dtype=int), np.nonzero(done)[0])
+        if isinstance(job, tuple):
+            pt = np.asarray(job[1], dtype=float).ravel()
+            grid = np.vstack((grid, pt[None, :]))
+            values, durations, done = np.append(values, np.nan), np.append(durations, np.nan), np.append(done, False)
+            idx = grid.shape[0] - 1
+            out.append((1, idx, pt))
+        else:
+            idx = int(job)
+            out.append((0, idx, grid[idx].copy()))
+        values[idx] = branin(grid[idx, 0], grid[idx, 1])
+        durations[idx] = 1.0 + 3.0 * grid[idx, 0] + np.sin(5 * grid[idx, 1]) ** 2
+        done[idx] = True
+        if type(ch).__name__ == "GPEIChooser" and getattr(ch, "D", -1) != -1:
+            ch.__del__()
+    return out

@@ -477,3 +477,12 @@ def test_restart_between_calls_on_gpu_matches_reference(golden_dir, tmp_path):
     """next(), a new chooser object on the same expt_dir, next(): the reference's two proposals, on the real engine."""
     from tests.test_host_logic import _two_call_runs
     _two_call_runs(golden_dir, tmp_path, lambda: None)
+
+
+@pytest.mark.parametrize("extra", ["", ",gpu_logprob=1,gpu_refine=1"])
+def test_whole_branin_runs_on_gpu_match_reference(golden_dir, tmp_path, extra):
+    """The reference's 24 + 14 consecutive Branin proposals (tests/golden/branin_trajectory.npz), reproduced with
+    the real engine -- by default (host log-likelihood / refinement below their size thresholds) and with the
+    device log-likelihood and the batched device refinement forced on."""
+    from tests.test_host_logic import _trajectory_runs
+    _trajectory_runs(golden_dir, tmp_path, lambda: None, extra)

@@ -391,6 +391,34 @@ def test_restart_between_calls_matches_reference(golden_dir, tmp_path):
     _two_call_runs(golden_dir, tmp_path, OracleEngine)
 
 
+def _trajectory_runs(golden_dir, tmp_path, make_engine, extra=""):
+    from tests.helpers import run_trajectory
+    g = _g(golden_dir, "branin_trajectory.npz")
+    for tag, mod, arg in (("g", GPEIChooser, "mcmc_iters=4"),
+                          ("o", GPEIOptChooser, "mcmc_iters=3,burnin=5,grid_subset=4,use_multiprocessing=0")):
+        d = tmp_path / tag
+        d.mkdir()
+
+        def make():
+            ch = mod.init(str(d), arg + extra)
+            eng = make_engine()
+            if eng is not None:
+                ch._eng = eng
+            return ch
+        props = run_trajectory(make, g["grid"], int(g[tag + "_iters"]), int(g[tag + "_seed"]))
+        assert [p[0] for p in props] == list(g[tag + "_new"])
+        assert [p[1] for p in props] == list(g[tag + "_idx"])
+        # refined points come out of L-BFGS runs (atol as in the single-call goldens), and each feeds the next call
+        assert np.allclose(np.array([p[2] for p in props]), g[tag + "_pts"], atol=2e-5)
+
+
+def test_whole_branin_runs_match_reference(golden_dir, tmp_path):
+    """24 / 14 consecutive proposals of GPEIChooser / GPEIOptChooser under a spearmint-lite-style loop (fresh
+    chooser per call, state pickle in between, new points appended): the same experiments, in the same order,
+    as the reference's own choosers produced with the same seeds."""
+    _trajectory_runs(golden_dir, tmp_path, OracleEngine)
+
+
 def test_noiseless_choosers_match_reference(golden_dir, tmp_path):
     """noiseless=1: noise pinned to 1e-3, joint slice move over [mean, amp2] only (GPEIChooser.py:268-270,
     :316-346): same hyper draws and proposals as the reference's own seeded runs."""
