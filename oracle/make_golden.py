@@ -25,7 +25,7 @@ Fixtures (all float64, ref = the reference's own functions):
   chooser_next_pending.npz  the same with three pending jobs (fantasy branch).
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
   chooser_next_noiseless.npz  seeded next() of the three choosers with noiseless=1.
-  branin_trajectory.npz  whole optimisation runs (24 / 14 proposals) of GPEIChooser / GPEIOptChooser on Branin.
+  branin_trajectory.npz  whole optimisation runs (24 / 14 / 12 proposals) of the three choosers on Branin.
   chooser_two_calls.npz  next(), restart from the state pickle with a new chooser object, next() again.
   chooser_next_ml2.npz  GPEIChooser.next with mcmc_iters=0 (ML-II hypers, gp.py:181-292).
   ei_grad.npz      the refinement objective: GPEIOptChooser.grad_optimize_ei_over_hypers
@@ -436,7 +436,8 @@ def gen_trajectory(mods, tmp):
     grid = np.transpose(sob.i4_sobol_generate(2, 400, 1))
     out = {"grid": grid}
     for tag, name, kw, iters, seed in (("g", "GPEIChooser", dict(mcmc_iters=4), 24, 7000),
-                                       ("o", "GPEIOptChooser", dict(mcmc_iters=3, burnin=5, grid_subset=4, use_multiprocessing=0), 14, 7100)):
+                                       ("o", "GPEIOptChooser", dict(mcmc_iters=3, burnin=5, grid_subset=4, use_multiprocessing=0), 14, 7100),
+                                       ("p", "GPEIperSecChooser", dict(mcmc_iters=2, burnin=4, grid_subset=3), 12, 7200)):
         d = tempfile.mkdtemp(prefix="spx_golden_traj_")
         props, vals, _ = run_trajectory(lambda: getattr(mods[name], name)(d, **kw), grid, iters, seed)
         out[tag + "_seed"], out[tag + "_iters"] = seed, iters

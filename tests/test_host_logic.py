@@ -395,7 +395,8 @@ def _trajectory_runs(golden_dir, tmp_path, make_engine, extra=""):
     from tests.helpers import run_trajectory
     g = _g(golden_dir, "branin_trajectory.npz")
     for tag, mod, arg in (("g", GPEIChooser, "mcmc_iters=4"),
-                          ("o", GPEIOptChooser, "mcmc_iters=3,burnin=5,grid_subset=4,use_multiprocessing=0")):
+                          ("o", GPEIOptChooser, "mcmc_iters=3,burnin=5,grid_subset=4,use_multiprocessing=0"),
+                          ("p", GPEIperSecChooser, "mcmc_iters=2,burnin=4,grid_subset=3,ref_compat=1")):
         d = tmp_path / tag
         d.mkdir()
 
@@ -413,7 +414,7 @@ def _trajectory_runs(golden_dir, tmp_path, make_engine, extra=""):
 
 
 def test_whole_branin_runs_match_reference(golden_dir, tmp_path):
-    """24 / 14 consecutive proposals of GPEIChooser / GPEIOptChooser under a spearmint-lite-style loop (fresh
+    """24 / 14 / 12 consecutive proposals of the three choosers under a spearmint-lite-style loop (fresh
     chooser per call, state pickle in between, new points appended): the same experiments, in the same order,
     as the reference's own choosers produced with the same seeds."""
     _trajectory_runs(golden_dir, tmp_path, OracleEngine)
