@@ -199,9 +199,17 @@ int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot);
  * in the order of spx_timing_name(i); returns the number of stages.            */
 int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n);
 const char* spx_timing_name(int i);
-/* tuning knobs: "kstar_budget_bytes" (K(X*,X) staging buffer; 0 = default), "streams" (1|2),
- * "timing" (0|1), "gemm_waves" (predict-GEMM variant of THIS handle; values the build does not
- * contain are rejected with SPX_ERR_ARG).                                                      */
+/* The correlation function of the GP -- the choosers' covar= argument, a function of
+ * spearmint/spearmint/gp.py selected by name (GPEIChooser.py:52): option "covar" of a handle.
+ * Every entry point (K, K*, log-likelihood, EI grid, EI gradient) follows it; changing it
+ * invalidates the factorisation.                                                             */
+#define SPX_COVAR_MATERN52 0   /* gp.Matern52 (gp.py:120-127), the default                     */
+#define SPX_COVAR_MATERN32 1   /* gp.Matern32 (gp.py:107-113)                                   */
+#define SPX_COVAR_ARDSE    2   /* gp.ARDSE    (gp.py:95-100)                                    */
+#define SPX_COVAR_SE       3   /* gp.SE       (gp.py:87-93): ARDSE with the length scales ignored */
+/* options: "covar" (SPX_COVAR_*); tuning knobs "kstar_budget_bytes" (K(X*,X) staging buffer;
+ * 0 = default), "streams" (1|2), "timing" (0|1), "gemm_waves" (predict-GEMM variant of THIS
+ * handle; values the build does not contain are rejected with SPX_ERR_ARG).                    */
 int spx_set_option(spx_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

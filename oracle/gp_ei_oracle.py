@@ -23,7 +23,33 @@ import numpy.random as npr
 import scipy.linalg as spla
 import scipy.stats as sps
 
+SQRT_3 = np.sqrt(3.0)  # S/gp.py:31
 SQRT_5 = np.sqrt(5.0)  # S/gp.py:32
+
+# The choosers pick their correlation function by name, getattr(gp, covar) (GPEIChooser.py:52); every
+# function below follows the module's ACTIVE one (default Matern52, the north star's).  Tests select
+# another with ``with covar("ARDSE"): ...``.
+COVARS = ("Matern52", "Matern32", "ARDSE", "SE")
+_active_covar = "Matern52"
+
+
+class covar(object):
+    """Context manager: the covariance function (a name from gp.py) used by everything in this module."""
+
+    def __init__(self, name):
+        if name not in COVARS:
+            raise AttributeError("gp has no covariance function %r" % (name,))
+        self.name = name
+
+    def __enter__(self):
+        global _active_covar
+        self.prev, _active_covar = _active_covar, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _active_covar
+        _active_covar = self.prev
+        return False
 
 
 # --------------------------------------------------------------------------
@@ -46,13 +72,34 @@ def matern52(ls, x1, x2=None):
     return (1.0 + SQRT_5 * r + (5.0 / 3.0) * r2) * np.exp(-SQRT_5 * r)
 
 
+def matern32(ls, x1, x2=None):
+    """S/gp.py:107-113."""
+    r = np.sqrt(dist2(ls, x1, x2))
+    return (1 + SQRT_3 * r) * np.exp(-SQRT_3 * r)
+
+
+def ardse(ls, x1, x2=None):
+    """S/gp.py:95-100."""
+    return np.exp(-0.5 * dist2(ls, x1, x2))
+
+
+def se(ls, x1, x2=None):
+    """S/gp.py:87-93: the length scales are replaced by ones."""
+    return np.exp(-0.5 * dist2(np.ones(np.shape(ls)), x1, x2))
+
+
+def corr(ls, x1, x2=None):
+    """self.cov_func = getattr(gp, covar) (GPEIChooser.py:52) for the active covariance."""
+    return {"Matern52": matern52, "Matern32": matern32, "ARDSE": ardse, "SE": se}[_active_covar](ls, x1, x2)
+
+
 def cov(amp2, ls, x1, x2=None):
     """Chooser covariance: jittered self-cov or plain cross-cov.
     S/chooser/GPEIChooser.py:117-122 (= GPEIOptChooser.py:207-212,
     GPEIperSecChooser.py:145-150)."""
     if x2 is None:
-        return amp2 * (matern52(ls, x1, None) + 1e-6 * np.eye(x1.shape[0]))
-    return amp2 * matern52(ls, x1, x2)
+        return amp2 * (corr(ls, x1, None) + 1e-6 * np.eye(x1.shape[0]))
+    return amp2 * corr(ls, x1, x2)
 
 
 # --------------------------------------------------------------------------
@@ -309,7 +356,7 @@ def gp_logprob(comp, vals, mean, amp2, noise, ls):
     """-sum(log diag L) - 0.5 r' K^-1 r, the data term shared by every
     sampler closure (GPEIChooser.py:281-285, :303-306)."""
     n = comp.shape[0]
-    c = amp2 * (matern52(ls, comp, None) + 1e-6 * np.eye(n)) + noise * np.eye(n)
+    c = amp2 * (corr(ls, comp, None) + 1e-6 * np.eye(n)) + noise * np.eye(n)
     chol = spla.cholesky(c, lower=True)
     solve = spla.cho_solve((chol, True), vals - mean)
     return -np.sum(np.log(np.diag(chol))) - 0.5 * np.dot(vals - mean, solve)
@@ -341,6 +388,26 @@ def grad_matern52(ls, x1, x2=None):
     return grad_r2[:, :, np.newaxis] * grad_dist2(ls, x1, x2)
 
 
+def grad_matern32(ls, x1, x2=None):
+    """S/gp.py:115-118."""
+    r = np.sqrt(dist2(ls, x1, x2))
+    grad_r2 = -1.5 * np.exp(-SQRT_3 * r)
+    return grad_r2[:, :, np.newaxis] * grad_dist2(ls, x1, x2)
+
+
+def grad_ardse(ls, x1, x2=None):
+    """S/gp.py:102-105."""
+    r2 = dist2(ls, x1, x2)
+    return -0.5 * np.exp(-0.5 * r2)[:, :, np.newaxis] * grad_dist2(ls, x1, x2)
+
+
+def grad_corr(ls, x1, x2=None):
+    """getattr(gp, 'grad_' + covar) (GPEIOptChooser.py:404): gp.py defines no grad_SE, so that raises."""
+    if _active_covar == "SE":
+        raise AttributeError("gp has no attribute 'grad_SE'")
+    return {"Matern52": grad_matern52, "Matern32": grad_matern32, "ARDSE": grad_ardse}[_active_covar](ls, x1, x2)
+
+
 def grad_optimize_ei(cand, comp, vals, hyper):
     """(-sum EI, gradient) at the point(s) ``cand`` under ONE hyper draw, no pending jobs.
     GPEIOptChooser.py:391-440, including its factor one half in grad_xp."""
@@ -351,7 +418,7 @@ def grad_optimize_ei(cand, comp, vals, hyper):
     cand_cross = cov(amp2, ls, comp, cand)
     obsv_cov = comp_cov + noise * np.eye(comp.shape[0])
     obsv_chol = spla.cholesky(obsv_cov, lower=True)
-    cand_cross_grad = grad_matern52(ls, comp, cand)
+    cand_cross_grad = grad_corr(ls, comp, cand)
     alpha = spla.cho_solve((obsv_chol, True), vals - mean)
     beta = spla.solve_triangular(obsv_chol, cand_cross, lower=True)
     func_m = np.dot(cand_cross.T, alpha) + mean
@@ -405,7 +472,7 @@ def grad_optimize_ei_fantasies(cand, comp_pend, hyper, fant_vals, bests):
     cp_cov = cov(amp2, ls, comp_pend) + noise * np.eye(comp_pend.shape[0])
     cp_chol = spla.cholesky(cp_cov, lower=True)
     cand_cross = cov(amp2, ls, comp_pend, cand)
-    cand_cross_grad = grad_matern52(ls, comp_pend, cand)
+    cand_cross_grad = grad_corr(ls, comp_pend, cand)
     alpha = spla.cho_solve((cp_chol, True), fant_vals - mean)
     beta = spla.solve_triangular(cp_chol, cand_cross, lower=True)
     func_m = np.dot(cand_cross.T, alpha) + mean
@@ -438,11 +505,11 @@ def grad_optimize_ei_per_s(cand, comp, vals, log_durs, hyper, time_hyper):
     obsv_time_chol = spla.cholesky(comp_time_cov + t_noise * np.eye(comp.shape[0]), lower=True)
     t_alpha = spla.cho_solve((obsv_time_chol, True), log_durs - t_mean)
     func_time_m = np.exp(np.dot(cand_time_cross.T, t_alpha) + t_mean)
-    grad_cross_t = np.squeeze(grad_matern52(t_ls, comp, cand))
+    grad_cross_t = np.squeeze(grad_corr(t_ls, comp, cand))
     comp_cov = cov(amp2, ls, comp)
     cand_cross = cov(amp2, ls, comp, cand)
     obsv_chol = spla.cholesky(comp_cov + noise * np.eye(comp.shape[0]), lower=True)
-    cand_cross_grad = grad_matern52(ls, comp, cand)
+    cand_cross_grad = grad_corr(ls, comp, cand)
     alpha = spla.cho_solve((obsv_chol, True), vals - mean)
     beta = spla.solve_triangular(obsv_chol, cand_cross, lower=True)
     func_m = np.dot(cand_cross.T, alpha) + mean

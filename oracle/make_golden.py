@@ -26,6 +26,8 @@ Fixtures (all float64, ref = the reference's own functions):
   slice_sampler.npz  util.slice_sample traces under a seeded RNG.
   chooser_next_noiseless.npz  seeded next() of the three choosers with noiseless=1.
   branin_trajectory.npz  whole optimisation runs (24 / 14 / 12 proposals) of the three choosers on Branin.
+  covar_{Matern32,ARDSE,SE}.npz  the other covar= choices: K, K*, EI (plain and with pending jobs), the
+                         refinement objective and seeded next() calls of the three choosers.
   chooser_two_calls.npz  next(), restart from the state pickle with a new chooser object, next() again.
   chooser_next_ml2.npz  GPEIChooser.next with mcmc_iters=0 (ML-II hypers, gp.py:181-292).
   ei_grad.npz      the refinement objective: GPEIOptChooser.grad_optimize_ei_over_hypers
@@ -449,6 +451,77 @@ def gen_trajectory(mods, tmp):
     np.savez_compressed(os.path.join(OUT, "branin_trajectory.npz"), **out)
 
 
+def gen_covar(mods, tmp):
+    """The other covariance functions a chooser can be built with (covar=, gp.py:87-118): stage arrays and EI of
+    compute_ei, the refinement objective, and whole seeded next() calls, all from the reference itself."""
+    for kname in ("Matern32", "ARDSE", "SE"):
+        out = {}
+        # (1) K, K*, EI
+        N, M, D, H = 80, 400, 4, 3
+        comp, cand, vals, hypers = synthetic_problem(N, M, D, H, 60 + len(kname))
+        ch = _mk_chooser(mods["GPEIChooser"], "GPEIChooser", tmp, mcmc_iters=H, covar=kname)
+        ch.D = D
+        pend = np.zeros((0, D))
+        ei = np.zeros((M, H)); K = np.zeros((H, N, N)); Kstar = np.zeros((H, N, M))
+        for h in range(H):
+            _set(ch, hypers[h])
+            ei[:, h] = ch.compute_ei(comp, pend, cand, vals)
+            K[h] = ch.cov(comp) + ch.noise * np.eye(N)
+            Kstar[h] = ch.cov(comp, cand)
+        out.update(comp=comp, cand=cand, vals=vals, hypers=hypers, ei=ei, K=K[0], Kstar=Kstar[0][:, :64],   # draw 0
+                   best=int(np.argmax(np.mean(ei, axis=1))))
+        # with two pending jobs (fantasies)
+        S = 9
+        chp = _mk_chooser(mods["GPEIChooser"], "GPEIChooser", tmp, mcmc_iters=H, covar=kname, pending_samples=S)
+        chp.D = D
+        pnd = np.random.RandomState(5).rand(2, D)
+        eip = np.zeros((M, H)); z = np.zeros((H, 2, S))
+        for h in range(H):
+            _set(chp, hypers[h])
+            npr.seed(300 + h)
+            z[h] = npr.randn(2, S)
+            npr.seed(300 + h)
+            eip[:, h] = chp.compute_ei(comp, pnd, cand, vals)
+        out.update(pend=pnd, randn=z, ei_pending=eip)
+        # (2) the refinement objective
+        opt = _mk_chooser(mods["GPEIOptChooser"], "GPEIOptChooser", tmp, mcmc_iters=H, covar=kname)
+        opt.D = D
+        _set(opt, hypers[0])
+        opt.hyper_samples = [(h[0], h[1], h[2], h[3:].copy()) for h in hypers]
+        rs = np.random.RandomState(7)
+        pts = np.vstack((cand[:3], comp[np.argmin(vals)] + 1e-3 * rs.randn(D), rs.rand(D)))
+        try:
+            f = np.zeros(len(pts)); g = np.zeros((len(pts), D))
+            for i, x in enumerate(pts):
+                f[i], g[i] = opt.grad_optimize_ei_over_hypers(x.copy(), comp, pend, vals)
+            out.update(points=pts, f=f, g=g, grad_raises=0)
+        except AttributeError as e:
+            print(kname, "refinement objective raises:", e)
+            out.update(points=pts, grad_raises=1)
+        # (3) whole next() calls on Branin
+        grid, values, durations, cnd, pnd_idx, cmp_idx = _branin_inputs(mods, 12, 300)
+        specs = [("g", "GPEIChooser", dict(mcmc_iters=3))]
+        if kname != "SE":
+            specs += [("o", "GPEIOptChooser", dict(mcmc_iters=3, burnin=4, grid_subset=3, use_multiprocessing=0)),
+                      ("p", "GPEIperSecChooser", dict(mcmc_iters=2, burnin=3, grid_subset=3))]
+        for tag, name, kw in specs:
+            for seed in range(1600, 1640):
+                c = getattr(mods[name], name)(tempfile.mkdtemp(prefix="spx_golden_cv_"), covar=kname, **kw)
+                npr.seed(seed)
+                try:
+                    job = c.next(grid, values, durations, cnd, pnd_idx, cmp_idx)
+                except Exception as e:
+                    print(kname, name, "seed", seed, "reference raised:", e)
+                    continue
+                out.update({tag + "_seed": seed, tag + "_is_new": int(isinstance(job, tuple)),
+                            tag + "_index": int(job[0] if isinstance(job, tuple) else job),
+                            tag + "_point": np.asarray(job[1] if isinstance(job, tuple) else grid[job]),
+                            tag + "_hyper": np.concatenate(([c.mean, c.noise, c.amp2], c.ls))})
+                break
+        out.update(grid=grid, values=values, durations=durations, candidates=cnd, pending=pnd_idx, complete=cmp_idx)
+        np.savez_compressed(os.path.join(OUT, "covar_%s.npz" % kname), **out)
+
+
 def gen_ei_grad(mods, tmp):
     """The L-BFGS-B objective of the local refinement, evaluated by the reference itself
     (GPEIOptChooser.py:360-525, GPEIperSecChooser.py:322-434)."""
@@ -508,7 +581,7 @@ def gen_ei_grad(mods, tmp):
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless, gen_two_calls, gen_trajectory):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless, gen_two_calls, gen_trajectory, gen_covar):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 

@@ -46,7 +46,7 @@ class GPEIChooser(GPEIBase):
             # back to the defaults if that fails, then score the grid once -- the same GPU call with
             # a single hyper row (argmax of a one-column mean == argmax(ei))
             try:
-                self.mean, self.amp2, self.noise, self.ls = hostgp.optimize_hypers(comp, vals)
+                self.mean, self.amp2, self.noise, self.ls = hostgp.optimize_hypers(comp, vals, self.covar)
             except Exception:
                 self.ls = np.ones(self.D)
                 self.amp2 = np.std(vals)

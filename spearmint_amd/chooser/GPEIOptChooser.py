@@ -123,6 +123,8 @@ class GPEIOptChooser(GPEIBase):
         spx_ei_grad_batch call against the factorisation (and, with pending jobs, the fantasies)
         the first EI pass left resident.  Tiny problems use host models, one point at a time."""
         bounds = [(0, 1)] * comp.shape[1]
+        if self.covar == "SE":   # getattr(gp, 'grad_SE') at :404 / :486
+            raise AttributeError("gp has no attribute 'grad_SE': the reference's refinement cannot run with covar=SE")
         if self._use_gpu_refine(comp.shape[0]):
             return refine.lbfgs_many(self.engine().ei_grad_batch, points, bounds, log=log)
         if pend.shape[0] > 0:
@@ -130,9 +132,9 @@ class GPEIOptChooser(GPEIBase):
             for h in self.hyper_samples:
                 npr.set_state(self.randomstate)
                 models.append(hostgp.PendingPointModel(comp, pend, vals, h,
-                                                       npr.randn(pend.shape[0], self.pending_samples)))
+                                                       npr.randn(pend.shape[0], self.pending_samples), self.covar))
         else:
-            models = [hostgp.PointModel(comp, vals, h) for h in self.hyper_samples]
+            models = [hostgp.PointModel(comp, vals, h, self.covar) for h in self.hyper_samples]
 
         def objective(x):
             total, grad = 0.0, np.zeros(x.shape[0])

@@ -149,13 +149,15 @@ class GPEIperSecChooser(GPEIBase):
         resident (spx_ei_grad); the bug-compatible mode pairs the draws as the reference does,
         which the resident pairing does not reproduce, so it stays on the host."""
         bounds = [(0, 1)] * comp.shape[1]
+        if self.covar == "SE":   # getattr(gp, 'grad_SE') at :383
+            raise AttributeError("gp has no attribute 'grad_SE': the reference's refinement cannot run with covar=SE")
         if self._use_gpu_refine(comp.shape[0]) and not self.ref_compat and self._resident_plain:
             return refine.lbfgs_many(self.engine().ei_grad_batch, points, bounds, log=log)
         else:
             rows, trows = (self.hyper_samples[:self.mcmc_iters],
                            (self.time_hyper_samples[:self.mcmc_iters] if self.ref_compat
                             else self.time_hyper_samples[-self.mcmc_iters:]))
-            models = [hostgp.PerSecPointModel(comp, vals, durs, h, t) for h, t in zip(rows, trows)]
+            models = [hostgp.PerSecPointModel(comp, vals, durs, h, t, self.covar) for h, t in zip(rows, trows)]
 
             def objective(x):
                 total, grad = 0.0, np.zeros(x.shape[0])

@@ -49,9 +49,10 @@ class GPEIBase(object):
     def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
                  noiseless=False, device=0, ndev=1, lib=None, gpu_logprob="auto", gpu_refine="auto",
                  lookahead=6, gpu_sobol=0, **unused):
-        if covar != "Matern52":
-            # the HIP path implements the ARD Matern-5/2 kernel named by the north star
-            raise ValueError("spearmint_amd choosers support covar=Matern52 only (got %r)" % (covar,))
+        if covar not in hostgp.COVARS:
+            # the reference does getattr(gp, covar) here (GPEIChooser.py:52)
+            raise AttributeError("no covariance function %r (gp.py has %s)" % (covar, ", ".join(hostgp.COVARS)))
+        self.covar = covar        # every kernel of gp.py runs on the GPU: option "covar" of the handle
         self.expt_dir = expt_dir
         self.locker = Locker()
         self.state_pkl = os.path.join(expt_dir, self.__module__ + ".pkl")
@@ -91,6 +92,7 @@ class GPEIBase(object):
                 self._eng = MultiEngine(range(self.device, self.device + self.ndev), self.lib_path)
             else:
                 self._eng = Engine(self.device, self.lib_path)
+            self._eng.set_covar(self.covar)
         return self._eng
 
     def __getstate__(self):
@@ -154,7 +156,7 @@ class GPEIBase(object):
         """-sum log diag L - 0.5 r'K^-1 r (GPEIChooser.py:281-285).  The slice sampler's
         control flow and RNG use stay on the host; only this O(N^3) term moves."""
         if not self._use_gpu_logprob(comp.shape[0]):
-            return hostgp.data_logprob(comp, vals, mean, amp2, noise, ls)
+            return hostgp.data_logprob(comp, vals, mean, amp2, noise, ls, self.covar)
         eng = self.engine()
         self._resident_observations(eng, comp, vals)
         eng.set_hypers(np.concatenate(([mean, noise, amp2], np.asarray(ls, dtype=float)))[None, :])
@@ -337,7 +339,7 @@ class GPEIBase(object):
         for h in range(H):
             chol = eng.get_factor(h, want_K=False, want_alpha=False)[1]
             fant[h], bests[h] = hostgp.fantasize_pending(comp, pend, vals, hyper_rows[h],
-                                                         chol[:n_comp, :n_comp], randn[h])
+                                                         chol[:n_comp, :n_comp], randn[h], self.covar)
         eng.set_fantasies(fant, bests)
         eng.ei_run()
         idx, _ = eng.best()

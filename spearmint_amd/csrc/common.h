@@ -19,6 +19,12 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define SPX_BK 16        // predict GEMM: contraction depth per LDS stage
 #define SPX_PADN 128     // observations are padded to a multiple of this
 
+// correlation function of the GP (gp.py:87-132; spx.h SPX_COVAR_*).  SE is ARDSE with unit length scales
+// (gp.py:88): the API layer substitutes the length scales, the kernels see ARDSE.
+#define SPX_COV_MATERN52 0
+#define SPX_COV_MATERN32 1
+#define SPX_COV_ARDSE 2
+
 // device hyper table row: [mean, noise, amp2, amp2*(1+1e-6)]
 #define SPX_HT 4
 
@@ -30,13 +36,14 @@ void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad,
                        const double* ls /*[nh][ls_stride]*/, int ls_stride, int nh, double factor,
                        double* xs /*[nh][n_pad][Dp]*/, double* sumsq /*[nh][n_pad]*/);
 void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const double* X2s,
-                     const double* htab, double* K, int N, int Np, int Dp, int nh, bool tiled = false);
+                     const double* htab, double* K, int N, int Np, int Dp, int nh, bool tiled = false,
+                     int kind = SPX_COV_MATERN52);
 void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                       const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
-                      int Dp, int nh);
+                      int Dp, int nh, int kind = SPX_COV_MATERN52);
 void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                        const double* s2, const double* htab, const double* alpha, double* out,
-                       int N, int Np, int Mc, int Dp, int nh);
+                       int N, int Np, int Mc, int Dp, int nh, int kind = SPX_COV_MATERN52);
 
 // chol_kernels.hip
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh, int updated = 0);
@@ -63,7 +70,7 @@ void launch_logprob(hipStream_t s, const double* L, const double* gamma, size_t 
 #define SPX_REFINE_PB 8   // points (right-hand sides) that share one pass over W in the refinement kernels
 void launch_point_cov(hipStream_t s, const double* Xs, const double* s1, const double* hyp,
                       const double* htab, const double* x, double* kvec, double* dkdr2, int N, int Np,
-                      int D, int Dp, int nh, int P);
+                      int D, int Dp, int nh, int P, int kind = SPX_COV_MATERN52);
 void launch_trimv_multi(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh, int P);
 void launch_trimvT_multi(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh, int P);
 void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, const double* htab,

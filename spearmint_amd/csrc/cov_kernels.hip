@@ -14,6 +14,7 @@
 #include "common.h"
 
 #define SQRT5 2.23606797749978969641  // == np.sqrt(5.0) (gp.py:32)
+#define SQRT3 1.73205080756887719318  // == np.sqrt(3.0) (gp.py:31)
 #ifndef SPX_COV_HOIST
 #define SPX_COV_HOIST 1   // keep the column-side fragments in registers across row tiles
 #endif
@@ -180,7 +181,53 @@ __device__ __forceinline__ void matern52_corr(const double (&g)[W], double s1, c
     }
 }
 
-template <int MODE, int QC>
+// Matern-3/2 (gp.py:107-113): r = sqrt(dist2); (1 + sqrt3 r) exp(-sqrt3 r).  Same clamps as above
+// (sqrt3 r > 800 beyond r2 = 2.1e5).
+template <int W>
+__device__ __forceinline__ void matern32_corr(const double (&g)[W], double s1, const double (&s2)[W],
+                                              double (&out)[W])
+{
+#pragma clang fp contract(off)
+    double t[W], r2[W], r[W], sr[W], e[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+#pragma unroll
+    for (int w = 0; w < W; ++w) r2[w] = __builtin_fmin(__builtin_fmax(-t[w], 1e-300), 2.1e5);
+    sqrt_pos<W>(r2, r);
+#pragma unroll
+    for (int w = 0; w < W; ++w) sr[w] = SQRT3 * r[w];
+    exp_neg<W>(sr, e);
+#pragma unroll
+    for (int w = 0; w < W; ++w) out[w] = fma(t[w], 0.0, (1.0 + sr[w]) * e[w]);
+}
+
+// squared exponential (gp.py:95-100; SE :87-93 is the same with unit length scales):
+// exp(-0.5 dist2); 0.5 r2 > 800 underflows to 0 either way.
+template <int W>
+__device__ __forceinline__ void ardse_corr(const double (&g)[W], double s1, const double (&s2)[W],
+                                           double (&out)[W])
+{
+#pragma clang fp contract(off)
+    double t[W], hr[W], e[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+#pragma unroll
+    for (int w = 0; w < W; ++w) hr[w] = 0.5 * __builtin_fmin(__builtin_fmax(-t[w], 0.0), 1600.0);
+    exp_neg<W>(hr, e);
+#pragma unroll
+    for (int w = 0; w < W; ++w) out[w] = fma(t[w], 0.0, e[w]);
+}
+
+template <int KIND, int W>
+__device__ __forceinline__ void corr_of_kind(const double (&g)[W], double s1, const double (&s2)[W],
+                                             double (&out)[W])
+{
+    if (KIND == SPX_COV_MATERN52) matern52_corr<W>(g, s1, s2, out);
+    else if (KIND == SPX_COV_MATERN32) matern32_corr<W>(g, s1, s2, out);
+    else ardse_corr<W>(g, s1, s2, out);
+}
+
+template <int MODE, int QC, int KIND>
 __global__ __launch_bounds__(256, 2) void k_cov(
     const double* __restrict__ Xs, const double* __restrict__ s1,
     const double* __restrict__ Cs, const double* __restrict__ s2,
@@ -228,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_cov(
             double gv[4], cv[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) gv[nt] = acc[nt][r];
-            matern52_corr<4>(gv, s1v, s2v, cv);
+            corr_of_kind<KIND, 4>(gv, s1v, s2v, cv);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int c = c0 + 16 * nt + li;
@@ -308,8 +355,8 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     }
 }
 
-template <int MODE>
-static void launch_cov_mode(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
+template <int MODE, int KIND>
+static void launch_cov_kind(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                             const double* s2, const double* htab, const double* alpha, double* out,
                             int N, int Np, int Mc, int Dp, int nh, int64_t ldo)
 {
@@ -318,7 +365,7 @@ static void launch_cov_mode(hipStream_t s, const double* Xs, const double* s1, c
     dim3 grid(Mc / 64, (MODE == 2) ? 1 : (Np + rows_per_wg - 1) / rows_per_wg, nh);
     dim3 block(256);
 #define SPX_COV_LAUNCH(QC_)                                                                        \
-    hipLaunchKernelGGL((k_cov<MODE, QC_>), grid, block, 0, s, Xs, s1, Cs, s2, htab, alpha, out, N, \
+    hipLaunchKernelGGL((k_cov<MODE, QC_, KIND>), grid, block, 0, s, Xs, s1, Cs, s2, htab, alpha, out, N, \
                        Np, Mc, Dp, Q / QC_, ldo, rows_per_wg)
     if (Q == 1) SPX_COV_LAUNCH(1);
     else if (Q == 2) SPX_COV_LAUNCH(2);
@@ -327,24 +374,37 @@ static void launch_cov_mode(hipStream_t s, const double* Xs, const double* s1, c
 #undef SPX_COV_LAUNCH
 }
 
+template <int MODE>
+static void launch_cov_mode(hipStream_t s, int kind, const double* Xs, const double* s1, const double* Cs,
+                            const double* s2, const double* htab, const double* alpha, double* out,
+                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo)
+{
+    if (kind == SPX_COV_MATERN32)
+        launch_cov_kind<MODE, SPX_COV_MATERN32>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo);
+    else if (kind == SPX_COV_ARDSE)
+        launch_cov_kind<MODE, SPX_COV_ARDSE>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo);
+    else
+        launch_cov_kind<MODE, SPX_COV_MATERN52>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo);
+}
+
 void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                       const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
-                      int Dp, int nh)
+                      int Dp, int nh, int kind)
 {
-    launch_cov_mode<0>(s, Xs, s1, Cs, s2, htab, nullptr, Kst, N, Np, Mc, Dp, nh, Mc);
+    launch_cov_mode<0>(s, kind, Xs, s1, Cs, s2, htab, nullptr, Kst, N, Np, Mc, Dp, nh, Mc);
 }
 
 // X2s = 2 * Xs (the reference multiplies the second operand by 2, gp.py:50)
 void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const double* X2s,
-                     const double* htab, double* K, int N, int Np, int Dp, int nh, bool tiled)
+                     const double* htab, double* K, int N, int Np, int Dp, int nh, bool tiled, int kind)
 {
-    if (tiled) launch_cov_mode<3>(s, Xs, s1, X2s, s1, htab, nullptr, K, N, Np, Np, Dp, nh, Np);
-    else launch_cov_mode<1>(s, Xs, s1, X2s, s1, htab, nullptr, K, N, Np, Np, Dp, nh, Np);
+    if (tiled) launch_cov_mode<3>(s, kind, Xs, s1, X2s, s1, htab, nullptr, K, N, Np, Np, Dp, nh, Np);
+    else launch_cov_mode<1>(s, kind, Xs, s1, X2s, s1, htab, nullptr, K, N, Np, Np, Dp, nh, Np);
 }
 
 void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                        const double* s2, const double* htab, const double* alpha, double* out,
-                       int N, int Np, int Mc, int Dp, int nh)
+                       int N, int Np, int Mc, int Dp, int nh, int kind)
 {
-    launch_cov_mode<2>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, Mc);
+    launch_cov_mode<2>(s, kind, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, Mc);
 }

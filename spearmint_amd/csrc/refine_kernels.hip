@@ -23,14 +23,17 @@
 #include "common.h"
 
 #define SQRT5 2.23606797749978969641
+#define SQRT3 1.73205080756887719318
 #define PB SPX_REFINE_PB   // right-hand sides that share one pass over W
 
-// k[h][p][j] = amp2 * matern(r_j), dkdr2[h][p][j] = -(5/6) exp(-sqrt5 r)(1 + sqrt5 r); pad rows -> 0
+// k[h][p][j] = amp2 * corr(r_j), dkdr2[h][p][j] = d corr / d r^2 (gp.py:102-105, :115-118, :129-132):
+//   Matern-5/2  -(5/6) exp(-sqrt5 r)(1 + sqrt5 r);  Matern-3/2  -1.5 exp(-sqrt3 r);  ARDSE  -0.5 exp(-r^2/2)
+// pad rows -> 0
 __global__ __launch_bounds__(256) void k_point_cov(
     const double* __restrict__ Xs /*[nh][Np][Dp]*/, const double* __restrict__ s1 /*[nh][Np]*/,
     const double* __restrict__ hyp /*[nh][3+D]*/, const double* __restrict__ htab,
     const double* __restrict__ x /*[P][D]*/, double* __restrict__ kvec, double* __restrict__ dkdr2,
-    int N, int Np, int D, int Dp, int P)
+    int N, int Np, int D, int Dp, int P, int kind)
 {
 #pragma clang fp contract(off)
     const int h = blockIdx.y, p = blockIdx.z;
@@ -54,9 +57,19 @@ __global__ __launch_bounds__(256) void k_point_cov(
         double r2 = (nt < 0.0) ? 0.0 : nt;
         r2 = fabs(r2);
         const double r = sqrt(r2);
-        const double e = exp(-SQRT5 * r);
-        kv = amp2 * (((1.0 + SQRT5 * r) + (5.0 / 3.0) * r2) * e);
-        dv = -(5.0 / 6.0) * e * (1.0 + SQRT5 * r);
+        if (kind == SPX_COV_MATERN52) {
+            const double e = exp(-SQRT5 * r);
+            kv = amp2 * (((1.0 + SQRT5 * r) + (5.0 / 3.0) * r2) * e);
+            dv = -(5.0 / 6.0) * e * (1.0 + SQRT5 * r);
+        } else if (kind == SPX_COV_MATERN32) {
+            const double e = exp(-SQRT3 * r);
+            kv = amp2 * ((1.0 + SQRT3 * r) * e);
+            dv = -1.5 * e;
+        } else {
+            const double e = exp(-0.5 * r2);
+            kv = amp2 * e;
+            dv = -0.5 * e;
+        }
     }
     const size_t o = ((size_t)h * P + p) * Np + j;
     kvec[o] = kv;
@@ -65,10 +78,10 @@ __global__ __launch_bounds__(256) void k_point_cov(
 
 void launch_point_cov(hipStream_t s, const double* Xs, const double* s1, const double* hyp,
                       const double* htab, const double* x, double* kvec, double* dkdr2, int N, int Np,
-                      int D, int Dp, int nh, int P)
+                      int D, int Dp, int nh, int P, int kind)
 {
     hipLaunchKernelGGL(k_point_cov, dim3((Np + 255) / 256, nh, P), dim3(256), 0, s, Xs, s1, hyp, htab, x,
-                       kvec, dkdr2, N, Np, D, Dp, P);
+                       kvec, dkdr2, N, Np, D, Dp, P, kind);
 }
 
 // out[h][p][i] = sum_{j <= i} WT_h[j][i] rhs[h][p][j]   (t = W k): one thread per row i, PB

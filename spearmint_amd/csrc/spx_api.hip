@@ -95,6 +95,9 @@ static int padded_dim(int D)
     return (int)round_up(D, 32);
 }
 
+// kernel-level correlation kind of a handle: SE runs as ARDSE on unit length scales (do_factor substitutes them)
+static inline int dev_kind(const spx_handle* h) { return h->cov_kind == SPX_COVAR_SE ? SPX_COV_ARDSE : h->cov_kind; }
+
 extern "C" {
 
 int spx_version(void) { return SPX_VERSION; }
@@ -158,6 +161,13 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         if (!predict_gemm_variant_ok((int)value))
             return fail(SPX_ERR_ARG, "spx_set_option: gemm_waves=%lld is not a variant of this build", (long long)value);
         h->gemm_variant = (int)value;
+        return SPX_OK;
+    }
+    if (!strcmp(name, "covar")) {   // SPX_COVAR_*: the reference's covar= (gp.py:87-132)
+        if (value < SPX_COVAR_MATERN52 || value > SPX_COVAR_SE)
+            return fail(SPX_ERR_ARG, "spx_set_option: covar=%lld is not one of SPX_COVAR_*", (long long)value);
+        if (h->cov_kind != (int)value) { h->factored = false; h->ran = false; h->S = 0; }
+        h->cov_kind = (int)value;
         return SPX_OK;
     }
     if (!strcmp(name, "streams")) {  // 1 = everything on one stream (default), 2 = alternate EI work items
@@ -266,6 +276,8 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
         for (int i = 0; i < H; ++i) {
             const double* r = &src[(size_t)i * hs];
             memcpy(&raw[((size_t)m * H + i) * hs], r, sizeof(double) * hs);
+            if (h->cov_kind == SPX_COVAR_SE)   // gp.SE ignores its length scales (gp.py:88)
+                for (int d = 0; d < D; ++d) raw[((size_t)m * H + i) * hs + 3 + d] = 1.0;
             double* t = &tab[((size_t)m * H + i) * SPX_HT];
             t[0] = r[0]; t[1] = r[1]; t[2] = r[2];
             t[3] = r[2] * (1 + 1e-6);  // self.amp2*(1+1e-6), GPEIChooser.py:199
@@ -302,7 +314,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     // tile-major copy of the matrix: one-step-deep launches instead of k sequential steps per tile, the
     // diagonal block factored inside the update launch (k_lean_step); same accumulation order, same bits.
     const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
-    TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, rl != 0));
+    TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, rl != 0, dev_kind(h)));
     // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
     // so y = L^-1 (vals - mean) is ready when the last column is
     double* rhs = nullptr;
@@ -518,7 +530,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
             TIMED_S(ST_SCALE, P, launch_scale_rows(P, xc, nreal, mc, D, Dp, ls + (size_t)H * hs, hs, H, 2.0, Cs, s2));
             TIMED_S(ST_CROSS_MEAN, P, launch_cross_mean(P, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np, Cs, s2,
                                                         h->htab.d() + (size_t)H * SPX_HT, h->alpha.d() + (size_t)H * Np, tm,
-                                                        (int)N, Np, mc, Dp, H));
+                                                        (int)N, Np, mc, Dp, H, dev_kind(h)));
         }
         if (per_sec && keep_mom)   // predicted durations [H][mc] -> [H][Mp] for spx_get_time_mean
             HIPCHK(hipMemcpy2DAsync(h->mom_t.d() + c0, (size_t)Mp * 8, tm, (size_t)mc * 8,
@@ -531,7 +543,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
             if (ns == 2 && item >= 2) HIPCHK(hipStreamWaitEvent(P, h->ev_sync[2 + k], 0));   // buffer k consumed
             TIMED_S(ST_COV_CROSS, P, launch_cov_cross(P, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
                                                       Cs + (size_t)h0 * mc * Dp, s2 + (size_t)h0 * mc,
-                                                      h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb));
+                                                      h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb, dev_kind(h)));
             if (ns == 2) {
                 HIPCHK(hipEventRecord(h->ev_sync[k], P));
                 HIPCHK(hipStreamWaitEvent(G, h->ev_sync[k], 0));
@@ -659,7 +671,7 @@ int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* al
         if ((rc = h->scratch.reserve(nn * 8))) return rc;
         launch_cov_self(h->stream, h->Xs.d() + (size_t)draw * Np * Dp, h->s1.d() + (size_t)draw * Np,
                         h->X2s.d() + (size_t)draw * Np * Dp, h->htab.d() + (size_t)draw * SPX_HT,
-                        h->scratch.d(), (int)N, Np, Dp, 1);
+                        h->scratch.d(), (int)N, Np, Dp, 1, false, dev_kind(h));
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy2D(K, (size_t)N * 8, h->scratch.p, (size_t)Np * 8, (size_t)N * 8, (size_t)N, hipMemcpyDeviceToHost));
     }
@@ -695,7 +707,7 @@ int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, doubl
     launch_scale_rows(s, h->cand.d() + (size_t)c0 * D, nc, mc, D, Dp, h->hyp.d() + 3 + (size_t)draw * hs, hs, 1, 2.0,
                       cs.d(), s2.d());
     launch_cov_cross(s, h->Xs.d() + (size_t)draw * Np * Dp, h->s1.d() + (size_t)draw * Np, cs.d(), s2.d(),
-                     h->htab.d() + (size_t)draw * SPX_HT, kst.d(), (int)h->N, Np, mc, Dp, 1);
+                     h->htab.d() + (size_t)draw * SPX_HT, kst.d(), (int)h->N, Np, mc, Dp, 1, dev_kind(h));
     hipError_t e = hipStreamSynchronize(s);
     if (e == hipSuccess)
         e = hipMemcpy2D(out, (size_t)nc * 8, kst.p, (size_t)mc * 8, (size_t)nc * 8, (size_t)h->N, hipMemcpyDeviceToHost);
@@ -831,13 +843,13 @@ int spx_ei_grad_batch(spx_handle* h, const double* points, int32_t P, double* ne
     }
     HIPCHK(hipMemcpyAsync(h->pt_x.p, points, (size_t)P * D * 8, hipMemcpyHostToDevice, s));
     launch_point_cov(s, h->Xs.d(), h->s1.d(), h->hyp.d(), h->htab.d(), h->pt_x.d(), h->pt_k.d(), h->pt_dk.d(),
-                     (int)N, Np, D, Dp, H, P);
+                     (int)N, Np, D, Dp, H, P, dev_kind(h));
     launch_trimv_multi(s, h->WT.d(), h->pt_k.d(), h->pt_t.d(), Np, H, P);        // t = W k
     launch_trimvT_multi(s, h->WT.d(), h->pt_t.d(), h->pt_z.d(), Np, H, P);       // z = W^T t = K^-1 k
     if (per_sec)   // k and dk/dr2 of the log-duration GP (table rows H..2H-1)
         launch_point_cov(s, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np,
                          h->hyp.d() + (size_t)H * (3 + D), h->htab.d() + (size_t)H * SPX_HT, h->pt_x.d(),
-                         h->pt_kt.d(), h->pt_dkt.d(), (int)N, Np, D, Dp, H, P);
+                         h->pt_kt.d(), h->pt_dkt.d(), (int)N, Np, D, Dp, H, P, dev_kind(h));
     launch_point_finish(s, h->Xs.d(), h->hyp.d(), h->htab.d(), h->alpha.d(), h->pt_k.d(), h->pt_dk.d(),
                         h->pt_t.d(), h->pt_z.d(), h->pt_x.d(), h->best, h->pt_out.d(), (int)N, Np, D, Dp, H, P,
                         per_sec ? h->pt_kt.d() : nullptr, per_sec ? h->pt_dkt.d() : nullptr, S,

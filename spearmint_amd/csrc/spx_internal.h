@@ -64,6 +64,7 @@ struct spx_handle {
     int not_pd_draw = -1, not_pd_pivot = -1;
     int64_t kst_budget = 512ll << 20;   // K(X*,X) staging buffer per stream (bytes)
     int nstreams = 1;
+    int cov_kind = 0;                   // SPX_COVAR_* (option "covar"); SE = ARDSE kernels on unit length scales
     int gemm_variant = 0;               // predict-GEMM variant of THIS handle (option "gemm_waves"); 0 = production
     struct spx_multi* multi = nullptr;  // non-null: this handle fronts several per-GPU handles (spx_multi.hip)
     struct spx_comm* comm = nullptr;    // non-null: one-process-per-GPU communicator attached (spx_comm_attach)

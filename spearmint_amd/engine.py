@@ -22,6 +22,8 @@ SPX_ERR_ARG = -1
 SPX_ERR_HIP = -2
 SPX_ERR_NOT_PD = -3
 
+COVAR = {"Matern52": 0, "Matern32": 1, "ARDSE": 2, "SE": 3}   # include/spx.h SPX_COVAR_*
+
 FLAG_PER_SEC = 1
 FLAG_KEEP_MOMENTS = 2
 FLAG_TIMING = 4
@@ -230,6 +232,12 @@ class Engine(object):
 
     def set_option(self, name, value):
         self._check(self._lib.spx_set_option(self._h, name.encode("ascii"), int(value)))
+
+    def set_covar(self, name):
+        """The GP's correlation function by its gp.py name (the choosers' covar=)."""
+        if name not in COVAR:
+            raise AttributeError("no covariance function %r (gp.py has %s)" % (name, ", ".join(sorted(COVAR))))
+        self.set_option("covar", COVAR[name])
 
     # -- hot path ---------------------------------------------------------
     def factor(self):

@@ -19,6 +19,8 @@ import scipy.linalg as spla
 import scipy.stats as sps
 
 ROOT5 = np.sqrt(5.0)
+ROOT3 = np.sqrt(3.0)
+COVARS = ("Matern52", "Matern32", "ARDSE", "SE")   # the reference's covar= choices (gp.py:87-132)
 
 
 def scaled_sqdist(ls, a, b=None):
@@ -50,22 +52,55 @@ def matern52_grad_wrt_first(ls, a, b):
     return dk_dr2[:, :, None] * dr2_da
 
 
-def obs_cov(amp2, noise, ls, x):
+def corr(covar, ls, a, b=None):
+    """The correlation function the chooser was built with: getattr(gp, covar) (GPEIChooser.py:52)."""
+    if covar == "Matern52":
+        return matern52(ls, a, b)
+    if covar == "Matern32":                                   # gp.py:107-113
+        r = np.sqrt(scaled_sqdist(ls, a, b))
+        return (1 + ROOT3 * r) * np.exp(-ROOT3 * r)
+    if covar == "ARDSE":                                      # gp.py:95-100
+        return np.exp(-0.5 * scaled_sqdist(ls, a, b))
+    if covar == "SE":                                         # gp.py:87-93: the length scales are ignored
+        return np.exp(-0.5 * scaled_sqdist(np.ones(np.shape(ls)), a, b))
+    raise AttributeError("no covariance function %r (gp.py has %s)" % (covar, ", ".join(COVARS)))
+
+
+def corr_grad_wrt_first(covar, ls, a, b):
+    """getattr(gp, 'grad_' + covar)(ls, a, b): d k(a_i, b_j) / d a_i, shape (Na, Nb, D)
+    (gp.py:102-105, :115-118, :129-132 with grad_dist2 :56-85).  There is no grad_SE in gp.py: the
+    reference's refinement raises AttributeError for covar=SE, and so does this."""
+    if covar == "Matern52":
+        return matern52_grad_wrt_first(ls, a, b)
+    if covar not in ("Matern32", "ARDSE"):
+        raise AttributeError("gp has no attribute 'grad_%s'" % (covar,))
+    sa = a / ls
+    sb = b / ls
+    r2 = scaled_sqdist(ls, a, b)
+    if covar == "Matern32":
+        dk_dr2 = -1.5 * np.exp(-ROOT3 * np.sqrt(r2))
+    else:
+        dk_dr2 = -0.5 * np.exp(-0.5 * r2)
+    dr2_da = 2.0 * (sa[:, None, :] - sb[None, :, :]) * (1.0 / ls)
+    return dk_dr2[:, :, None] * dr2_da
+
+
+def obs_cov(amp2, noise, ls, x, covar="Matern52"):
     """amp2 (k + 1e-6 I) + noise I  (GPEIChooser.py:117-122, :190)."""
     n = x.shape[0]
-    return amp2 * (matern52(ls, x) + 1e-6 * np.eye(n)) + noise * np.eye(n)
+    return amp2 * (corr(covar, ls, x) + 1e-6 * np.eye(n)) + noise * np.eye(n)
 
 
-def data_logprob(x, y, mean, amp2, noise, ls):
+def data_logprob(x, y, mean, amp2, noise, ls, covar="Matern52"):
     """-sum log diag L - 0.5 r^T K^-1 r  (GPEIChooser.py:281-285).
     Lets numpy.linalg.LinAlgError propagate, as the reference does."""
-    chol = spla.cholesky(obs_cov(amp2, noise, ls, x), lower=True)
+    chol = spla.cholesky(obs_cov(amp2, noise, ls, x, covar), lower=True)
     resid = y - mean
     sol = spla.cho_solve((chol, True), resid)
     return -np.sum(np.log(np.diag(chol))) - 0.5 * np.dot(resid, sol)
 
 
-def optimize_hypers(comp, vals):
+def optimize_hypers(comp, vals, covar="Matern52"):
     """ML-II point estimate of (mean, amp2, noise, ls) -- the ``mcmc_iters=0`` branch of the
     reference (gp.GP.optimize_hypers, gp.py:181-292, called from GPEIChooser.py:158-160).
     Host-side by design: it runs once per ``next`` and is not on the EI hot path.
@@ -95,10 +130,12 @@ def optimize_hypers(comp, vals):
     def factor(amp2, noise, ls):
         if ("corr" not in memo or memo["amp2"] != amp2 or memo["noise"] != noise
                 or np.any(memo["ls"] != ls)):
-            corr = matern52(ls, comp)
-            grad_corr = matern52_grad_wrt_first(ls, comp, comp)
-            covmat = amp2 * (corr + 1e-6 * eye) + noise * eye
-            memo.update(corr=corr, grad_corr=grad_corr, chol=jittered_cholesky(covmat),
+            kmat = corr(covar, ls, comp)
+            # cov_func(ls, comp, None, grad=True): SE pairs its value with grad_ARDSE on unit length scales (gp.py:88-91)
+            grad_corr = (corr_grad_wrt_first("ARDSE", np.ones(np.shape(ls)), comp, comp) if covar == "SE"
+                         else corr_grad_wrt_first(covar, ls, comp, comp))
+            covmat = amp2 * (kmat + 1e-6 * eye) + noise * eye
+            memo.update(corr=kmat, grad_corr=grad_corr, chol=jittered_cholesky(covmat),
                         amp2=amp2, noise=noise, ls=ls)
         return memo["chol"], memo["corr"], memo["grad_corr"]
 
@@ -139,12 +176,13 @@ class PointModel(object):
     """Posterior at ONE hyper draw, factorised once, for evaluating EI and its
     gradient at a handful of points during local refinement."""
 
-    def __init__(self, comp, vals, hyper):
+    def __init__(self, comp, vals, hyper, covar="Matern52"):
+        self.covar = covar
         self.mean, self.noise, self.amp2 = float(hyper[0]), float(hyper[1]), float(hyper[2])
         self.ls = np.asarray(hyper[3], dtype=float)
         self.comp = comp
         self.best = np.min(vals)
-        self.chol = spla.cholesky(obs_cov(self.amp2, self.noise, self.ls, comp), lower=True)
+        self.chol = spla.cholesky(obs_cov(self.amp2, self.noise, self.ls, comp, covar), lower=True)
         self.alpha = spla.cho_solve((self.chol, True), vals - self.mean)
 
     def neg_ei_and_grad(self, x):
@@ -152,7 +190,7 @@ class PointModel(object):
         GPEIOptChooser.py:391-440 returns 0.5 x the analytic gradient (its
         grad_xp carries an extra factor one half); L-BFGS-B sees exactly that."""
         x = np.reshape(x, (-1, self.comp.shape[1]))
-        kx = self.amp2 * matern52(self.ls, self.comp, x)
+        kx = self.amp2 * corr(self.covar, self.ls, self.comp, x)
         beta = spla.solve_triangular(self.chol, kx, lower=True)
         m = np.dot(kx.T, self.alpha) + self.mean
         v = self.amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
@@ -161,7 +199,7 @@ class PointModel(object):
         cdf = sps.norm.cdf(u)
         pdf = sps.norm.pdf(u)
         ei = s * (u * cdf + pdf)
-        dk = np.squeeze(matern52_grad_wrt_first(self.ls, self.comp, x))
+        dk = np.squeeze(corr_grad_wrt_first(self.covar, self.ls, self.comp, x))
         d_m = np.dot(self.alpha.T, dk)
         d_v = np.dot(-2 * spla.cho_solve((self.chol, True), kx).T, dk)
         grad = 0.5 * self.amp2 * (d_m * (-cdf) + d_v * (0.5 * pdf / s))
@@ -172,21 +210,21 @@ class PerSecPointModel(PointModel):
     """PointModel plus the log-duration GP (mean only) for EI-per-second
     refinement (GPEIperSecChooser.py:349-434)."""
 
-    def __init__(self, comp, vals, log_durs, hyper, time_hyper):
-        PointModel.__init__(self, comp, vals, hyper)
+    def __init__(self, comp, vals, log_durs, hyper, time_hyper, covar="Matern52"):
+        PointModel.__init__(self, comp, vals, hyper, covar)
         self.t_mean, self.t_noise, self.t_amp2 = (float(time_hyper[0]), float(time_hyper[1]),
                                                   float(time_hyper[2]))
         self.t_ls = np.asarray(time_hyper[3], dtype=float)
-        t_chol = spla.cholesky(obs_cov(self.t_amp2, self.t_noise, self.t_ls, comp), lower=True)
+        t_chol = spla.cholesky(obs_cov(self.t_amp2, self.t_noise, self.t_ls, comp, covar), lower=True)
         self.t_alpha = spla.cho_solve((t_chol, True), log_durs - self.t_mean)
 
     def neg_ei_and_grad(self, x):
         x = np.reshape(x, (-1, self.comp.shape[1]))
-        kt = self.t_amp2 * matern52(self.t_ls, self.comp, x)
+        kt = self.t_amp2 * corr(self.covar, self.t_ls, self.comp, x)
         time_m = np.exp(np.dot(kt.T, self.t_alpha) + self.t_mean)
-        dkt = np.squeeze(matern52_grad_wrt_first(self.t_ls, self.comp, x))
+        dkt = np.squeeze(corr_grad_wrt_first(self.covar, self.t_ls, self.comp, x))
 
-        kx = self.amp2 * matern52(self.ls, self.comp, x)
+        kx = self.amp2 * corr(self.covar, self.ls, self.comp, x)
         beta = spla.solve_triangular(self.chol, kx, lower=True)
         m = np.dot(kx.T, self.alpha) + self.mean
         v = self.amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
@@ -195,7 +233,7 @@ class PerSecPointModel(PointModel):
         cdf = sps.norm.cdf(u)
         pdf = sps.norm.pdf(u)
         ei = s * (u * cdf + pdf)
-        dk = np.squeeze(matern52_grad_wrt_first(self.ls, self.comp, x))
+        dk = np.squeeze(corr_grad_wrt_first(self.covar, self.ls, self.comp, x))
         d_m = np.dot(self.alpha.T, dk)
         d_v = np.dot(-2 * spla.cho_solve((self.chol, True), kx).T, dk)
         g = 0.5 * self.amp2 * (d_m * (-cdf) + d_v * (0.5 * pdf / s))
@@ -204,7 +242,7 @@ class PerSecPointModel(PointModel):
         return -np.sum(ei / time_m), g.flatten()
 
 
-def fantasize_pending(comp, pend, vals, hyper_row, obsv_chol, randn_ps):
+def fantasize_pending(comp, pend, vals, hyper_row, obsv_chol, randn_ps, covar="Matern52"):
     """Host part of the pending branch (GPEIChooser.py:219-249), O(N^2 P):
     posterior of the P pending points given the N completed ones, S joint
     fantasy outcomes.  `obsv_chol` is the N x N leading block of the Cholesky
@@ -214,8 +252,8 @@ def fantasize_pending(comp, pend, vals, hyper_row, obsv_chol, randn_ps):
     mean, noise, amp2 = hyper_row[0], hyper_row[1], hyper_row[2]
     ls = np.asarray(hyper_row[3:], dtype=float)
     p = pend.shape[0]
-    pend_cross = amp2 * matern52(ls, comp, pend)
-    pend_kappa = amp2 * (matern52(ls, pend) + 1e-6 * np.eye(p))
+    pend_cross = amp2 * corr(covar, ls, comp, pend)
+    pend_kappa = amp2 * (corr(covar, ls, pend) + 1e-6 * np.eye(p))
     alpha = spla.cho_solve((obsv_chol, True), vals - mean)
     beta = spla.cho_solve((obsv_chol, True), pend_cross)
     pend_m = np.dot(pend_cross.T, alpha) + mean
@@ -231,20 +269,21 @@ class PendingPointModel(object):
     """EI (averaged over fantasies) and its gradient at a few points, with
     pending experiments -- the host-side refinement of GPEIOptChooser.py:441-525."""
 
-    def __init__(self, comp, pend, vals, hyper, randn_ps):
+    def __init__(self, comp, pend, vals, hyper, randn_ps, covar="Matern52"):
+        self.covar = covar
         self.mean, self.noise, self.amp2 = float(hyper[0]), float(hyper[1]), float(hyper[2])
         self.ls = np.asarray(hyper[3], dtype=float)
         self.comp_pend = np.concatenate((comp, pend))
         n = comp.shape[0]
-        self.chol = spla.cholesky(obs_cov(self.amp2, self.noise, self.ls, self.comp_pend), lower=True)
+        self.chol = spla.cholesky(obs_cov(self.amp2, self.noise, self.ls, self.comp_pend, covar), lower=True)
         row = np.concatenate(([self.mean, self.noise, self.amp2], self.ls))
-        fant_vals, self.bests = fantasize_pending(comp, pend, vals, row, self.chol[:n, :n], randn_ps)
+        fant_vals, self.bests = fantasize_pending(comp, pend, vals, row, self.chol[:n, :n], randn_ps, covar)
         self.alpha = spla.cho_solve((self.chol, True), fant_vals - self.mean)
 
     def neg_ei_and_grad(self, x):
         d = self.comp_pend.shape[1]
         x = np.reshape(x, (-1, d))
-        kx = self.amp2 * matern52(self.ls, self.comp_pend, x)
+        kx = self.amp2 * corr(self.covar, self.ls, self.comp_pend, x)
         beta = spla.solve_triangular(self.chol, kx, lower=True)
         m = np.dot(kx.T, self.alpha) + self.mean
         v = self.amp2 * (1 + 1e-6) - np.sum(beta ** 2, axis=0)
@@ -253,7 +292,7 @@ class PendingPointModel(object):
         cdf = sps.norm.cdf(u)
         pdf = sps.norm.pdf(u)
         ei = s * (u * cdf + pdf)
-        dk = np.squeeze(matern52_grad_wrt_first(self.ls, self.comp_pend, x), axis=1)
+        dk = np.squeeze(corr_grad_wrt_first(self.covar, self.ls, self.comp_pend, x), axis=1)
         d_m = np.dot(self.alpha.T, dk)
         d_v = np.dot(-2 * spla.cho_solve((self.chol, True), kx).T, dk)
         g = 0.5 * self.amp2 * (d_m * np.tile(-cdf, (d, 1)).T + (d_v.T * (0.5 * pdf / s)).T)

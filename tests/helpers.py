@@ -8,9 +8,13 @@ from oracle import gp_ei_oracle as orc
 
 
 class OracleEngine(object):
-    def __init__(self):
+    def __init__(self, covar="Matern52"):
         self.calls = []
         self.fant = None
+        self.covar = covar
+
+    def set_covar(self, name):
+        self.covar = name
 
     # -- resident-data mode (what the pending path of the choosers uses) ------------
     def set_observations(self, comp, vals):
@@ -106,6 +110,18 @@ class OracleEngine(object):
         idx = int(np.argmax(mean))
         self.calls.append(("ei_per_sec_grid", cand.shape[0], np.atleast_2d(hypers).shape[0]))
         return idx, float(mean[idx]), mean, (ei if want_draws else None)
+
+
+def _under_covar(fn):
+    def wrapped(self, *a, **k):
+        with orc.covar(self.covar):
+            return fn(self, *a, **k)
+    wrapped.__name__ = fn.__name__
+    return wrapped
+
+
+for _name in ("get_time_mean", "factor", "ei_run", "ei_grid", "ei_grad_batch", "ei_per_sec_grid"):
+    setattr(OracleEngine, _name, _under_covar(getattr(OracleEngine, _name)))
 
 
 def np_mean_device_order(row):

@@ -166,9 +166,52 @@ def test_persec_next_with_pending_matches_reference(golden_dir, tmp_path):
         assert job == int(g["p_index"])
 
 
-def test_unsupported_covariance_rejected(tmp_path):
-    with pytest.raises(ValueError):
-        GPEIChooser.init(str(tmp_path), "covar=ARDSE")
+def test_unknown_covariance_rejected(tmp_path):
+    with pytest.raises(AttributeError):            # the reference: getattr(gp, covar)
+        GPEIChooser.init(str(tmp_path), "covar=Periodic")
+
+
+def _covar_runs(golden_dir, tmp_path, kname, make_engine, extra=""):
+    g = _g(golden_dir, "covar_%s.npz" % kname)
+    args = (g["grid"], g["values"], g["durations"], g["candidates"], g["pending"], g["complete"])
+    specs = [("g", GPEIChooser, "mcmc_iters=3")]
+    if kname != "SE":
+        specs += [("o", GPEIOptChooser, "mcmc_iters=3,burnin=4,grid_subset=3,use_multiprocessing=0"),
+                  ("p", GPEIperSecChooser, "mcmc_iters=2,burnin=3,grid_subset=3,ref_compat=1")]
+    for tag, mod, arg in specs:
+        d = tmp_path / (kname + tag)
+        d.mkdir()
+        ch = mod.init(str(d), arg + ",covar=" + kname + extra)
+        eng = make_engine(kname)
+        if eng is not None:
+            ch._eng = eng
+        npr.seed(int(g[tag + "_seed"]))
+        job = ch.next(*args)
+        assert np.allclose(np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)), g[tag + "_hyper"], rtol=1e-6)
+        if int(g[tag + "_is_new"]):
+            assert isinstance(job, tuple) and job[0] == int(g[tag + "_index"])
+            assert np.allclose(job[1], g[tag + "_point"], atol=1e-5)
+        else:
+            assert job == int(g[tag + "_index"])
+    if kname == "SE":      # no grad_SE in gp.py: the reference's refinement raises, and so does ours
+        for mod, arg in ((GPEIOptChooser, "mcmc_iters=2,burnin=2,grid_subset=2,use_multiprocessing=0"),
+                         (GPEIperSecChooser, "mcmc_iters=2,burnin=2,grid_subset=2")):
+            d = tmp_path / (kname + mod.__name__.split(".")[-1])
+            d.mkdir()
+            ch = mod.init(str(d), arg + ",covar=SE" + extra)
+            eng = make_engine(kname)
+            if eng is not None:
+                ch._eng = eng
+            npr.seed(1)
+            with pytest.raises(AttributeError):
+                ch.next(*args)
+
+
+@pytest.mark.parametrize("kname", ["Matern32", "ARDSE", "SE"])
+def test_choosers_with_other_covariances_match_reference(golden_dir, tmp_path, kname):
+    """covar=Matern32 / ARDSE / SE: the reference's own seeded next() calls (hyper draws through the slice
+    sampler, EI grid, refinement) reproduced by our choosers."""
+    _covar_runs(golden_dir, tmp_path, kname, lambda k: OracleEngine(k))
 
 
 @pytest.mark.parametrize("H", [1, 3, 7, 8, 9, 10, 16, 20, 31, 128, 129, 300])

@@ -164,3 +164,30 @@ def test_refinement_objective_is_a_gradient():
         num = (orc.grad_optimize_ei_over_hypers(x + e, comp, vals, hypers)[0]
                - orc.grad_optimize_ei_over_hypers(x - e, comp, vals, hypers)[0]) / 2e-6
         assert np.isclose(0.5 * num, gr[d], rtol=1e-4, atol=1e-10)
+
+
+@pytest.mark.parametrize("kname", ["Matern32", "ARDSE", "SE"])
+def test_other_covariances_match_reference(golden_dir, kname):
+    """covar= Matern32 / ARDSE / SE (gp.py:87-118): K, K*, EI, the pending branch and the refinement objective
+    of the reference's own choosers built with that covariance."""
+    g = _load(golden_dir, "covar_%s.npz" % kname)
+    with orc.covar(kname):
+        st = {}
+        orc.compute_ei(g["comp"], g["cand"], g["vals"], g["hypers"][0], stages=st)
+        _close(st["K"], g["K"])
+        _close(st["Kstar"][:, :64], g["Kstar"])
+        ei = orc.ei_over_hypers(g["comp"], g["cand"], g["vals"], g["hypers"])
+        _close(ei, g["ei"], rtol=1e-9)
+        assert orc.choose(ei) == int(g["best"])
+        for h in range(g["hypers"].shape[0]):
+            eip = orc.compute_ei_pending(g["comp"], g["pend"], g["cand"], g["vals"], g["hypers"][h], g["randn"][h])
+            _close(eip, g["ei_pending"][:, h], rtol=1e-9)
+        if int(g["grad_raises"]):
+            with pytest.raises(AttributeError):       # gp.py has no grad_SE
+                orc.grad_optimize_ei_over_hypers(g["points"][0], g["comp"], g["vals"], g["hypers"])
+        else:
+            for x, f_ref, g_ref in zip(g["points"], g["f"], g["g"]):
+                f, gr = orc.grad_optimize_ei_over_hypers(x, g["comp"], g["vals"], g["hypers"])
+                assert np.isclose(f, f_ref, rtol=1e-12, atol=0) and np.allclose(gr, g_ref, rtol=1e-10, atol=1e-300)
+    # the default is untouched afterwards
+    assert orc._active_covar == "Matern52"
