@@ -518,6 +518,11 @@ def gen_covar(mods, tmp):
                             tag + "_point": np.asarray(job[1] if isinstance(job, tuple) else grid[job]),
                             tag + "_hyper": np.concatenate(([c.mean, c.noise, c.amp2], c.ls))})
                 break
+        # (4) mcmc_iters=0: ML-II hypers (gp.GP(covar).optimize_hypers) + one EI pass, GPEIChooser
+        c = mods["GPEIChooser"].GPEIChooser(tempfile.mkdtemp(prefix="spx_golden_cv_"), covar=kname, mcmc_iters=0)
+        npr.seed(5)
+        out.update(ml2_job=int(c.next(grid, values, durations, cnd, pnd_idx, cmp_idx)),
+                   ml2_hyper=np.concatenate(([c.mean, c.noise, c.amp2], c.ls)))
         out.update(grid=grid, values=values, durations=durations, candidates=cnd, pending=pnd_idx, complete=cmp_idx)
         np.savez_compressed(os.path.join(OUT, "covar_%s.npz" % kname), **out)
 

@@ -193,6 +193,16 @@ def _covar_runs(golden_dir, tmp_path, kname, make_engine, extra=""):
             assert np.allclose(job[1], g[tag + "_point"], atol=1e-5)
         else:
             assert job == int(g[tag + "_index"])
+    # mcmc_iters=0: the ML-II point estimate under this covariance
+    d = tmp_path / (kname + "ml2")
+    d.mkdir()
+    ch = GPEIChooser.init(str(d), "mcmc_iters=0,covar=" + kname + extra)
+    eng = make_engine(kname)
+    if eng is not None:
+        ch._eng = eng
+    npr.seed(5)
+    assert ch.next(*args) == int(g["ml2_job"])
+    assert np.allclose(np.concatenate(([ch.mean, ch.noise, ch.amp2], ch.ls)), g["ml2_hyper"], rtol=1e-6)
     if kname == "SE":      # no grad_SE in gp.py: the reference's refinement raises, and so does ours
         for mod, arg in ((GPEIOptChooser, "mcmc_iters=2,burnin=2,grid_subset=2,use_multiprocessing=0"),
                          (GPEIperSecChooser, "mcmc_iters=2,burnin=2,grid_subset=2")):
