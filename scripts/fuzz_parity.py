@@ -1,5 +1,5 @@
 """Randomised parity sweep: GPU engine vs the CPU oracle on random shapes (dev tool, GPU box).
-python scripts/fuzz_parity.py [n_cases] [seed]"""
+python scripts/fuzz_parity.py [n_cases] [seed] [covar: Matern52 | Matern32 | ARDSE | SE | mix]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,10 +11,14 @@ from spearmint_amd import sobol
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 123)
+covar_arg = sys.argv[3] if len(sys.argv) > 3 else "Matern52"
 eng = Engine(0)
 worst = 0.0
 t0 = time.time()
 for c in range(ncases):
+    kname = str(rs.choice(["Matern52", "Matern32", "ARDSE", "SE"])) if covar_arg == "mix" else covar_arg
+    eng.set_covar(kname)
+    ctx = orc.covar(kname); ctx.__enter__()
     N = int(rs.choice([2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 255, 257, 383, 511, 700, 1025, 1500, 2049]))
     M = int(rs.choice([10, 11, 63, 64, 65, 127, 129, 500, 1000, 4097, 20001]))
     D = int(rs.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 40]))
@@ -42,8 +46,9 @@ for c in range(ncases):
     flag = "" if (err < 1e-5 and ok_arg and lerr < 1e-9) else "   <-- FAIL"
     if not flag and err >= 1e-7:
         flag = "   (ill-conditioned: > 1e-7)"
-    print("case %2d N=%4d M=%5d D=%2d H=%d per_sec=%d  ei rel err %.2e  logprob rel err %.1e  argmax %s%s"
-          % (c, N, M, D, H, per_sec, err, lerr, ok_arg, flag))
+    ctx.__exit__()
+    print("case %2d %-8s N=%4d M=%5d D=%2d H=%d per_sec=%d  ei rel err %.2e  logprob rel err %.1e  argmax %s%s"
+          % (c, kname, N, M, D, H, per_sec, err, lerr, ok_arg, flag))
 # Sobol: random (dim, n, skip)
 for c in range(10):
     table = "bf40" if rs.rand() < 0.5 else "jk1111"
