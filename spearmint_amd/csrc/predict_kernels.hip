@@ -291,6 +291,188 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_predict_gemm_tri: the production tiling (128 x 128, 2 x 2 waves, LDS-DMA staging) that also skips the
+// structurally zero part of W's diagonal block.  In the K step that covers columns 16 d .. 16 d + 15 of the
+// diagonal block of row block ib, the 16-row tiles t < d of W are zero.  Two things make skipping them pay:
+//   * the two wave rows own the 16-row tiles ALTERNATELY (wave row wm: tiles wm, wm + 2, wm + 4, wm + 6), so
+//     both lose tiles at the same pace (live tiles per wave 4,4 / 3,4 / 3,3 / 2,3 / 2,2 / 1,2 / 1,1 / 0,1 for
+//     d = 0..7) -- with contiguous halves the lower wave row keeps all its tiles until d = 4 and the barrier
+//     makes the idle upper one wait for it;
+//     (that, and not the branches, is why skipping never paid with the contiguous layout);
+//   * the code of a full step is untouched: a diagonal step takes a second copy of the step body.
+// Full steps run the same code as k_predict_gemm; a diagonal step takes a second copy of the step body whose
+// MFMA groups are entered at the first live tile (wave-uniform jump).  The K order is unchanged; the row
+// ownership changes the order of the epilogue's floating-point sums, nothing else.  What did NOT work on the
+// way here (C3, ms per launch, 1.85-1.87 for k_predict_gemm on the same box): the same skip with the four waves
+// side by side (128 x 32 each, every wave the same triangular profile) 1.89 even before skipping; one
+// straight-line copy of the step per skip count 1.99 (256 VGPRs); the short steps spread between the full ones
+// 1.83-1.85; this form 1.80.
+__global__ __launch_bounds__(256, 2) void k_predict_gemm_tri(
+    const double* __restrict__ WT, const double* __restrict__ Kst,
+    const double* __restrict__ gamma, double* __restrict__ part_ss,
+    double* __restrict__ part_bg, int Np, int Mc, int nh, int ncb, int nrb,
+    int part_nh, int part_h0, const double* __restrict__ gammaS, int S, double* __restrict__ part_bgS)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                      // [2][BK][LDT]
+    double* Bs = smem + 2 * BK * LDT;       // [2][BK][LDT]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the skip below is a scalar jump
+    const int g = lane >> 4, li = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int NW = 4, NQ = 4;
+
+    const int ncbx = (ncb + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int per_rb = ncbx * nh;
+    const int ib = nrb - 1 - slot / per_rb;
+    const int rem = slot % per_rb;
+    const int h = rem / ncbx;
+    const int cb = (rem % ncbx) * 8 + xcd;
+    if (cb >= ncb) return;
+
+    const double* Ag = WT + (size_t)h * Np * Np + (size_t)ib * BM;
+    const double* Bg = Kst + (size_t)h * Np * Mc + (size_t)cb * BN;
+    const int nk = (ib + 1) * (BM / BK);
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    d4 acc[4][4];        // acc[mt][nt]: rows 16 (2 mt + wm) + g + 4 r, columns 64 wn + 16 nt + li
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+#define SPX_DMA_TILE(KT_, BUF_)                                                                            \
+    {                                                                                                      \
+        const size_t j0_ = (size_t)(KT_) * BK;                                                             \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
+            const int row = wave + NW * q;                                                                 \
+            __builtin_amdgcn_global_load_lds(Ag + (j0_ + row) * Np + 2 * lane,                             \
+                                             (lds_void_t*)(As + (BUF_) * BK * LDT + row * LDT), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds(Bg + (j0_ + row) * Mc + 2 * lane,                             \
+                                             (lds_void_t*)(Bs + (BUF_) * BK * LDT + row * LDT), 16, 0, 0); \
+        }                                                                                                  \
+    }
+    SPX_DMA_TILE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nfull = nk - BM / BK;           // the last 8 K steps cover the diagonal block
+    int cur = 0;
+    // ONE loop over all K steps, on purpose: with the rectangular part peeled into a loop of its own (the
+    // exact loop of k_predict_gemm) the compiler's schedule of both loops gets worse (2.03 ms per launch at
+    // C3 instead of 1.80).
+    for (int j = 0; j < nk; ++j) {
+        // diagonal step d = j - nfull covers columns 16 d .. 16 d + 15 of the diagonal block; first live tile
+        // of this wave: tiles 2 mt + wm >= d  <=>  mt >= (d - wm + 1) >> 1   (4: none)
+        const int m0 = (j >= nfull) ? ((j - nfull - wm + 1) >> 1) : 0;
+        if (j + 1 < nk) SPX_DMA_TILE(j + 1, cur ^ 1)
+        const double* Ac = As + cur * BK * LDT + 16 * wm + li;
+        const double* Bc = Bs + cur * BK * LDT + 64 * wn + li;
+        if (m0 == 0) {
+#pragma unroll
+            for (int k0 = 0; k0 < BK; k0 += 4) {
+                double a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = Bc[(k0 + g) * LDT + 16 * t];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[t] = Ac[(k0 + g) * LDT + 32 * t];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA_F64(a[mt], b[nt], acc[mt][nt]);
+            }
+            // (the wait + barrier are repeated in both branches so that the compiler can, as in
+            // k_predict_gemm, sink the last MFMA group of a full step below them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+#define SPX_TRI_G4(MT_)                                                      \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[MT_][nt] = MFMA_F64(a[MT_], b[nt], acc[MT_][nt]);
+#pragma unroll
+            for (int k0 = 0; k0 < BK; k0 += 4) {
+                double a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = Bc[(k0 + g) * LDT + 16 * t];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[t] = Ac[(k0 + g) * LDT + 32 * t];
+                switch (m0) {            // one copy of the MFMAs, entered at the first live tile
+                    case 1: SPX_TRI_G4(1)
+                    case 2: SPX_TRI_G4(2)
+                    case 3: SPX_TRI_G4(3)
+                    default: break;
+                }
+            }
+#undef SPX_TRI_G4
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        cur ^= 1;
+    }
+#undef SPX_DMA_TILE
+
+    // ---- epilogue: column sums of C^2 and C*gamma over this wave row's 64 rows, then the two wave rows ----
+    const double* gh = gamma + (size_t)h * Np + (size_t)ib * BM + 16 * wm;
+    double gam[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gam[mt][r] = gh[32 * mt + g + 4 * r];
+    double* red = smem;  // [2 (wm)][128][2]; safe: every wave passed the last barrier of the K loop
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        double ss = 0.0, bg = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = acc[mt][nt][r];
+                ss = fma(v, v, ss);
+                bg = fma(v, gam[mt][r], bg);
+            }
+        ss += __shfl_xor(ss, 16);
+        bg += __shfl_xor(bg, 16);
+        ss += __shfl_xor(ss, 32);
+        bg += __shfl_xor(bg, 32);
+        if (g == 0) {
+            const int c = 64 * wn + 16 * nt + li;
+            red[(wm * BN + c) * 2 + 0] = ss;
+            red[(wm * BN + c) * 2 + 1] = bg;
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        const size_t o = ((size_t)ib * part_nh + part_h0 + h) * Mc + (size_t)cb * BN + tid;
+        part_ss[o] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+        part_bg[o] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+    }
+    if (S > 0) {   // pending-experiment fantasies: one partial per wave row, summed by k_ei_finalize_fant
+        const double* gS = gammaS + (size_t)h * S * Np + (size_t)ib * BM + 16 * wm;
+        double* outS = part_bgS + ((((size_t)ib * 2 + wm) * nh + h) * S) * Mc + (size_t)cb * BN + 64 * wn;
+        for (int sidx = 0; sidx < S; ++sidx) {
+            const double* gs = gS + (size_t)sidx * Np;
+            double gv[4][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[mt][r] = gs[32 * mt + g + 4 * r];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                double bg = 0.0;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bg = fma(acc[mt][nt][r], gv[mt][r], bg);
+                bg += __shfl_xor(bg, 16);
+                bg += __shfl_xor(bg, 32);
+                if (g == 0) outS[(size_t)sidx * Mc + 16 * nt + li] = bg;
+            }
+        }
+    }
+}
+
 // Variants (spx_set_option "gemm_waves", per handle): 0 / 14 = production (4 waves, LDS-DMA staging,
 // measured fastest), 4 / 8 = 4 / 8 waves with register staging, 18 = 8 waves with LDS-DMA, 24 = LDS-DMA
 // with three 8-row buffers and two tiles in flight.  They agree to rounding (the 8-wave kernels sum the
@@ -300,7 +482,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_predict_gemm(
 bool predict_gemm_variant_ok(int v)
 {
     switch (v) {
-        case 0: case 4: case 8: case 14: case 18: case 24: return true;
+        case 0: case 4: case 8: case 14: case 18: case 24: case 32: return true;
 #ifdef SPX_ABLATIONS
         case 41: case 42: case 43: case 44: return true;
 #endif
@@ -331,7 +513,14 @@ void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const dou
 #define SPX_GO(NW_, STG_, ABL_)                                                                               \
     launch_gemm_variant<NW_, STG_, ABL_>(s, grid, lds, WT, Kst, gamma, part_ss, part_bg, Np, Mc, nh, ncb, nrb, \
                                          part_nh, part_h0, gammaS, S, part_bgS)
-    const int v = (S > 0) ? 0 : variant;   // the fantasy epilogue exists in the 4-wave kernels
+    const int v = (S > 0 && variant != 32) ? 0 : variant;   // the fantasy epilogue exists in the 4-wave kernels
+    if (v == 32) {   // 2 x 2 waves, alternating row tiles, zero tiles of the diagonal block skipped
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm_tri),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_predict_gemm_tri, dim3(grid), dim3(256), lds, s, WT, Kst, gamma, part_ss, part_bg, Np, Mc,
+                           nh, ncb, nrb, part_nh, part_h0, gammaS, S, part_bgS);
+        return;
+    }
     switch (v) {
         case 8:  SPX_GO(8, 0, 0); break;
         case 18: SPX_GO(8, 1, 0); break;
