@@ -473,8 +473,9 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm_tri(
     }
 }
 
-// Variants (spx_set_option "gemm_waves", per handle): 0 / 14 = production (4 waves, LDS-DMA staging,
-// measured fastest), 4 / 8 = 4 / 8 waves with register staging, 18 = 8 waves with LDS-DMA, 24 = LDS-DMA
+// Variants (spx_set_option "gemm_waves", per handle): 0 / 32 = production (k_predict_gemm_tri: 4 waves, LDS-DMA
+// staging, zero tiles of the diagonal block skipped -- measured fastest), 14 = the same without the skipping
+// (k_predict_gemm; production until round 2), 4 / 8 = 4 / 8 waves with register staging, 18 = 8 waves with LDS-DMA, 24 = LDS-DMA
 // with three 8-row buffers and two tiles in flight.  They agree to rounding (the 8-wave kernels sum the
 // row groups of the epilogue in another order).  The
 // timing-only ablations 41..44 (WRONG results, for performance analysis) exist only in a library
@@ -513,8 +514,10 @@ void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const dou
 #define SPX_GO(NW_, STG_, ABL_)                                                                               \
     launch_gemm_variant<NW_, STG_, ABL_>(s, grid, lds, WT, Kst, gamma, part_ss, part_bg, Np, Mc, nh, ncb, nrb, \
                                          part_nh, part_h0, gammaS, S, part_bgS)
-    const int v = (S > 0 && variant != 32) ? 0 : variant;   // the fantasy epilogue exists in the 4-wave kernels
-    if (v == 32) {   // 2 x 2 waves, alternating row tiles, zero tiles of the diagonal block skipped
+    // 0 = production: k_predict_gemm_tri.  The rectangular kernels have the fantasy epilogue in their 4-wave
+    // form only (14 = the round-1 production kernel: 4 waves, LDS-DMA staging).
+    const int v = (S > 0 && variant != 0 && variant != 32) ? 14 : variant;
+    if (v == 0 || v == 32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm_tri),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_predict_gemm_tri, dim3(grid), dim3(256), lds, s, WT, Kst, gamma, part_ss, part_bg, Np, Mc,
@@ -532,7 +535,7 @@ void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const dou
         case 43: SPX_GO(4, 0, 3); break;
         case 44: SPX_GO(4, 1, 4); break;
 #endif
-        default: SPX_GO(4, 1, 0); break;   // production: 4 waves, LDS-DMA staging
+        default: SPX_GO(4, 1, 0); break;   // 14: 4 waves, LDS-DMA staging, no skipping (production until round 2)
     }
 #undef SPX_GO
 }
