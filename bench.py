@@ -28,8 +28,8 @@ candidate grid of these is generated in fixed seeded blocks, so every N scores
 the same grid and must report the same best_index.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel
-(k_predict_gemm: beta = L^-1 K* as an fp64 MFMA GEMM with the variance/mean
-reduction fused in its epilogue): achieved = algorithmic flops per launch
+(k_predict_gemm_tri: beta = L^-1 K* as an fp64 MFMA GEMM over the lower triangle of
+L^-1, with the variance/mean reduction fused in its epilogue): achieved = algorithmic flops per launch
 (N^2 + 4N per (candidate, draw) evaluation) / the kernel's mean
 launch duration, measured with HIP events on the library's own stream over a
 second timed pass of the same steps (the headline pass runs without per-launch
@@ -344,7 +344,7 @@ def main():
         evals_per_launch = evals_per_step * ev_steps / gemm_n
         achieved = flops_per_eval * evals_per_launch / avg_s / 1e12
         traffic, traffic_src = pmc_traffic(args.workload) if world == 1 else (None, None)
-        roofline = {"bound": "mfma", "kernel": "k_predict_gemm", "achieved": achieved,
+        roofline = {"bound": "mfma", "kernel": "k_predict_gemm_tri", "achieved": achieved,
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_source": traffic_src, "peak_measured_ubench": FP64_MFMA_MEASURED_TFLOPS,
