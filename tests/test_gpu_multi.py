@@ -338,3 +338,35 @@ def test_process_group_communicator_attached_to_a_handle(eng):
     _, c2, v2, h2, s0 = bench.weak_problem(w, 0)
     idx, val, _, _ = eng.ei_grid(c2, v2, s0, h2)
     assert (out["best_index"], out["best_ei"]) == (idx, val)
+
+
+def test_handles_release_their_device_memory():
+    """Create / use / destroy handles in a loop (every buffer family: plain EI, per second, fantasies, refinement,
+    log-likelihood, Sobol): the device's free memory comes back, so spx_destroy's buffer list is complete."""
+    import torch
+    from spearmint_amd.engine import Engine
+    from spearmint_amd import sobol
+    comp, cand, vals, hypers, ld, th = synthetic_problem(300, 20000, 6, 3, 77, per_sec=True)
+    rs = np.random.RandomState(0)
+
+    def cycle():
+        e = Engine(0)
+        e.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        e.ei_per_sec_grid(comp, vals, ld, cand, hypers, th)
+        e.ei_grad_batch(cand[:5])
+        e.set_observations(comp, vals); e.set_candidates(cand); e.set_hypers(hypers); e.factor()
+        e.set_fantasies(rs.randn(3, 300, 9), rs.randn(3, 9))
+        e.ei_run(); e.ei_grad_batch(cand[:3])
+        e.set_hypers(hypers); e.gp_logprob()
+        e.sobol_grid(sobol.load_dirs("bf40"), 8, 50000, 1)
+        e.close()
+
+    for _ in range(4):          # the runtime keeps some freed blocks for reuse: let that settle first
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(12):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < (16 << 20), "leaked %.1f MiB over 12 handle lifetimes" % ((free0 - free1) / 2.0 ** 20)
