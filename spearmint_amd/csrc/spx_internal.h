@@ -18,9 +18,11 @@ int spx_fail(int code, const char* fmt, ...);
 #define HIPCHK(call)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess)                                                                 \
+        if (e_ != hipSuccess) {                                                               \
+            (void)hipGetLastError(); /* reported now: the runtime's sticky copy is cleared */   \
             return fail(SPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
                         __FILE__, __LINE__);                                                  \
+        }                                                                                     \
     } while (0)
 
 // grow-only device buffer
@@ -32,8 +34,11 @@ struct DevBuf {
         if (bytes <= cap) return SPX_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess)
+        if (e != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();   // reported here; do not leave it for the next call's launch check to find
             return fail(SPX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        }
         cap = bytes;
         return SPX_OK;
     }

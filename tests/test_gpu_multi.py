@@ -370,3 +370,24 @@ def test_handles_release_their_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(0)[0]
     assert free0 - free1 < (16 << 20), "leaked %.1f MiB over 12 handle lifetimes" % ((free0 - free1) / 2.0 ** 20)
+
+
+def test_out_of_device_memory_is_an_error_code_not_a_crash(eng):
+    """A K(X*,X) staging budget the device cannot satisfy (315 GB asked of 288 GB): the call returns the HIP error
+    through spx_last_error -> SpxError, and the same handle works again once the budget is sane."""
+    from spearmint_amd.engine import SpxError
+    comp, cand, vals, hypers = synthetic_problem(4096, 600000, 4, 16, 78)
+    eng.set_observations(comp, vals); eng.set_candidates(cand); eng.set_hypers(hypers); eng.factor()
+    eng.set_option("kstar_budget_bytes", 1 << 40)
+    try:
+        with pytest.raises(SpxError) as err:
+            eng.ei_run()
+        assert "hipMalloc" in str(err.value)
+    finally:
+        eng.set_option("kstar_budget_bytes", 0)     # back to the default
+    eng.ei_run()
+    idx, val = eng.best()
+    sub = np.r_[idx, 0:200]
+    ref = orc.ei_over_hypers(comp, cand[sub], vals, hypers)
+    got = eng.ei_mean()[sub]
+    assert np.allclose(got, np.mean(ref, axis=1), rtol=1e-6, atol=1e-300)
