@@ -391,3 +391,27 @@ def test_out_of_device_memory_is_an_error_code_not_a_crash(eng):
     ref = orc.ei_over_hypers(comp, cand[sub], vals, hypers)
     got = eng.ei_mean()[sub]
     assert np.allclose(got, np.mean(ref, axis=1), rtol=1e-6, atol=1e-300)
+
+
+def test_handle_survives_argument_and_numerical_errors(eng):
+    """Every error is a return code; the handle keeps working afterwards, with unchanged results."""
+    from numpy.linalg import LinAlgError
+    comp, cand, vals, hypers = synthetic_problem(150, 3000, 5, 3, 79)
+    ref = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    bad = hypers.copy(); bad[1, 2] = -1.0                      # negative amplitude: not positive definite
+    with pytest.raises(LinAlgError):
+        eng.ei_grid(comp, vals, cand, bad)
+    with pytest.raises(ValueError):
+        eng.ei_grid(comp, vals, cand[:, :4], hypers)           # candidates of another dimension
+    with pytest.raises(ValueError):
+        eng.ei_grid(comp, vals, cand, hypers[:, :6])           # hyper rows too short
+    eng.set_observations(comp, vals); eng.set_hypers(hypers)
+    with pytest.raises(ValueError):
+        eng.ei_run()                                           # nothing factored
+    with pytest.raises(ValueError):
+        eng.ei_grad_batch(cand[:2])                            # no resident factorisation either
+    lp = eng.gp_logprob()                                      # -inf is a value here, not an error
+    eng.set_hypers(bad)
+    assert np.isneginf(eng.gp_logprob()[1]) and np.array_equal(eng.gp_logprob()[[0, 2]], lp[[0, 2]])
+    again = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    assert again[0] == ref[0] and np.array_equal(again[3], ref[3])
