@@ -338,21 +338,26 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm_tri(
     const double* Bg = Kst + (size_t)h * Np * Mc + (size_t)cb * BN;
     const int nk = (ib + 1) * (BM / BK);
     typedef __attribute__((address_space(3))) void lds_void_t;
+    const unsigned loff = (unsigned)lane * 16u;   // this lane's 16 bytes of a 1 KiB tile row
     d4 acc[4][4];        // acc[mt][nt]: rows 16 (2 mt + wm) + g + 4 r, columns 64 wn + 16 nt + li
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
 
+    // LDS-DMA of one 1 KiB tile row in the SGPR-base form (wave-uniform row address + this lane's 32-bit byte
+    // offset), written as asm because the builtin always materialises a 64-bit VGPR address: that is one
+    // 64-bit VALU add per DMA instruction, and every VALU instruction in this loop costs MFMA issue time.
+#define SPX_DMA_ROW(GPTR_, LPTR_)                                                                          \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                          \
+                 :: "v"(loff), "s"(GPTR_), "s"((unsigned)(size_t)(lds_void_t*)(LPTR_)) : "memory")   /* m0 is reserved: the compiler never keeps anything in it */
 #define SPX_DMA_TILE(KT_, BUF_)                                                                            \
     {                                                                                                      \
         const size_t j0_ = (size_t)(KT_) * BK;                                                             \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
             const int row = wave + NW * q;                                                                 \
-            __builtin_amdgcn_global_load_lds(Ag + (j0_ + row) * Np + 2 * lane,                             \
-                                             (lds_void_t*)(As + (BUF_) * BK * LDT + row * LDT), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds(Bg + (j0_ + row) * Mc + 2 * lane,                             \
-                                             (lds_void_t*)(Bs + (BUF_) * BK * LDT + row * LDT), 16, 0, 0); \
+            SPX_DMA_ROW(Ag + (j0_ + row) * Np, As + (BUF_) * BK * LDT + row * LDT);                        \
+            SPX_DMA_ROW(Bg + (j0_ + row) * Mc, Bs + (BUF_) * BK * LDT + row * LDT);                        \
         }                                                                                                  \
     }
     SPX_DMA_TILE(0, 0)
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm_tri(
         cur ^= 1;
     }
 #undef SPX_DMA_TILE
+#undef SPX_DMA_ROW
 
     // ---- epilogue: column sums of C^2 and C*gamma over this wave row's 64 rows, then the two wave rows ----
     const double* gh = gamma + (size_t)h * Np + (size_t)ib * BM + 16 * wm;
