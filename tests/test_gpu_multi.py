@@ -415,3 +415,30 @@ def test_handle_survives_argument_and_numerical_errors(eng):
     assert np.isneginf(eng.gp_logprob()[1]) and np.array_equal(eng.gp_logprob()[[0, 2]], lp[[0, 2]])
     again = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
     assert again[0] == ref[0] and np.array_equal(again[3], ref[3])
+
+
+def test_plain_c_client_of_the_abi(eng, tmp_path):
+    """tests/c/abi_client.c -- C99, gcc, no Python, no C++ -- drives libspx through include/spx.h and gets, bit for
+    bit, what the ctypes binding gets: the boundary is a C ABI, not a Python extension."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "spearmint_amd")
+    exe = str(tmp_path / "abi_client")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_client.c"), "-o", exe,
+                           "-L" + libdir, "-lspx", "-Wl,-rpath," + libdir])
+    comp, cand, vals, hypers = synthetic_problem(300, 7000, 6, 4, 80)
+    with open(str(tmp_path / "in.bin"), "wb") as fh:
+        np.array([300, 6, 7000, 4], dtype=np.int64).tofile(fh)
+        for a in (comp, vals, cand, hypers):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(fh)
+    out = subprocess.check_output([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    raw = open(str(tmp_path / "out.bin"), "rb").read()
+    best_idx = int(np.frombuffer(raw, dtype=np.int64, count=1)[0])
+    rest = np.frombuffer(raw, dtype=np.float64, offset=8)
+    best_val, mean, draws, lp = rest[0], rest[1:7001], rest[7001:7001 + 28000].reshape(7000, 4), rest[7001 + 28000:]
+    idx, val, m, d = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    eng.set_hypers(hypers)
+    assert best_idx == idx and best_val == val and np.array_equal(mean, m) and np.array_equal(draws, d)
+    assert np.array_equal(lp, eng.gp_logprob())
+    assert out.decode().startswith("best %d " % idx)
