@@ -477,3 +477,22 @@ def test_noiseless_choosers_match_reference(golden_dir, tmp_path):
     """noiseless=1: noise pinned to 1e-3, joint slice move over [mean, amp2] only (GPEIChooser.py:268-270,
     :316-346): same hyper draws and proposals as the reference's own seeded runs."""
     _noiseless_runs(golden_dir, tmp_path, OracleEngine)
+
+
+def test_host_code_parses_with_the_python2_grammar():
+    """The reference driver is Python 2.7 (README.md:25): the chooser package, its helpers and the drop-in shims stay
+    in the 2/3 common subset -- here: every file parses with lib2to3's Python 2 grammar."""
+    import glob
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lib2to3 = pytest.importorskip("lib2to3")
+        from lib2to3 import pygram, pytree
+        from lib2to3.pgen2 import driver
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = driver.Driver(pygram.python_grammar, convert=pytree.convert)
+    files = (glob.glob(os.path.join(root, "spearmint_amd", "*.py")) + glob.glob(os.path.join(root, "spearmint_amd", "chooser", "*.py"))
+             + glob.glob(os.path.join(root, "dropin", "chooser", "*.py")))
+    assert len(files) > 10
+    for f in files:
+        drv.parse_string(open(f).read() + "\n")
