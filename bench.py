@@ -216,6 +216,9 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--skip-extras", action="store_true", help="do not time the strong-scaling c4 / c5 sub-records")
     ap.add_argument("--extra-steps", type=int, default=2, help="timed steps of each strong-scaling sub-record (after 1 warm-up)")
+    ap.add_argument("--hyper-shards", type=int, default=1,
+                    help="N > 1 only: also time C4 in the optional 2-D partition of SURVEY 8(e) -- draws x candidates over "
+                         "P_h x (N / P_h) ranks, one all-reduce(SUM) of the M-vector of EI sums (sub-record c4_2d)")
     ap.add_argument("--c4-candidates", type=int, default=STRONG["c4"]["M"])
     ap.add_argument("--c5-candidates", type=int, default=STRONG["c5"]["M"])
     ap.add_argument("--event-steps", type=int, default=3, help="steps of the second (per-launch HIP event) pass")
@@ -435,6 +438,37 @@ def main():
                                         "D": cfg["D"], "mcmc_iters": cfg["H"], "per_sec": cfg["per_sec"]},
                              "best_index": sbest[0], "best_ei": sbest[1]}
                 out["%s_value" % name] = sval
+
+    # ---- optional: C4 in the 2-D (draws x candidates) partition, one all-reduce(SUM) of the EI-sum vector ----------
+    if args.hyper_shards > 1 and world > 1 and not args.skip_extras:
+        cfg = dict(STRONG["c4"])
+        cfg["M"] = int(args.c4_candidates)
+        sprob, scomp, svals, shyp = strong_problem(cfg)
+        (lo, hi), (h0, h1) = spx_dist.shard_2d(cfg["M"], cfg["H"], world, rank, args.hyper_shards)
+        rows = strong_rows(cfg, scomp, svals, lo, hi)
+        e3 = Engine(local_rank)
+        e3.set_observations(scomp, svals)
+        e3.set_candidates(rows, index_base=lo)
+        e3.set_hypers(shyp[h0:h1])
+
+        def step_2d():
+            e3.factor()
+            e3.ei_run(0)
+            sums = np.sum(e3.ei_draws(), axis=1)          # this rank's draws, its candidates
+            return spx_dist.allreduce_ei_sums(sums, lo, cfg["M"], cfg["H"], device=tdev)
+        step_2d()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.extra_steps):
+            r2 = step_2d()
+        sync()
+        dt2 = max_over_ranks(time.perf_counter() - t0)
+        e3.close()
+        if rank == 0:
+            out["c4_2d"] = {"value": float(cfg["M"]) * cfg["H"] * args.extra_steps / dt2, "unit": "EI evals/s",
+                            "scaling": "strong", "n_gpus": world, "partition": "%d draw shards x %d candidate shards"
+                            % spx_dist.grid_2d(world, args.hyper_shards), "collective": "all-reduce(SUM) of %d doubles" % cfg["M"],
+                            "ms_per_step": dt2 / args.extra_steps * 1e3, "best_index": r2[0], "best_ei": r2[1]}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -78,3 +78,49 @@ def exchange_best(local_value, local_index, device=None, group=None):
 
 
 allreduce_best = exchange_best   # round-1 name
+
+
+# ---- optional 2-D partition: draws x candidates ("hypers x candidates") --------------
+# P = P_h x P_c ranks: rank r = rc * P_h + rh evaluates the draws of hyper shard rh for the candidates of
+# shard rc.  The single collective is then an all-reduce(SUM) of the zero-padded M-vector of per-candidate EI
+# sums (8 M bytes), after which EVERY rank holds sum_h EI[c, h] for every candidate and takes the argmax
+# locally.  It pays when replicating the H factorisations on every rank is significant (large N, few
+# candidates per rank); the price is that the sum over draws is no longer numpy's pairwise order but "local
+# sums, then the reduction tree", so means can differ from the 1-D scheme in the last bits (ties and near-ties
+# may resolve differently; everything else is the same number to ~1e-16 relative).
+def grid_2d(world_size, hyper_shards):
+    """(P_h, P_c) for `world_size` ranks; hyper_shards must divide world_size."""
+    ph = int(hyper_shards)
+    if ph < 1 or world_size % ph:
+        raise ValueError("hyper_shards=%d does not divide world_size=%d" % (ph, world_size))
+    return ph, world_size // ph
+
+
+def shard_2d(M, H, world_size, rank, hyper_shards):
+    """This rank's piece of the (draws x candidates) product: ((c_lo, c_hi), (h_lo, h_hi))."""
+    ph, pc = grid_2d(world_size, hyper_shards)
+    rh, rc = rank % ph, rank // ph
+    return shard_bounds(M, pc, rc), shard_bounds(H, ph, rh)
+
+
+def allreduce_ei_sums(local_sums, c_lo, M, H, device=None, group=None):
+    """The one collective of the 2-D scheme.  local_sums[c - c_lo] = sum over THIS rank's draws of EI[c, h] for
+    its candidates; returns (global_index, mean EI value, mean vector) -- identical on every rank -- where
+    mean[c] = (sum over all ranks) / H and the index follows numpy's argmax rule."""
+    full = np.zeros(int(M), dtype=np.float64)
+    full[c_lo:c_lo + len(local_sums)] = local_sums
+    try:
+        import torch
+        import torch.distributed as dist
+        live = dist.is_available() and dist.is_initialized()
+    except ImportError:  # pragma: no cover
+        live = False
+    if live:
+        t = torch.from_numpy(full)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        full = t.cpu().numpy()
+    mean = full / float(H)
+    idx = int(np.argmax(mean))
+    return idx, float(mean[idx]), mean

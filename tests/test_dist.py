@@ -96,3 +96,55 @@ def test_strong_scaling_grid_does_not_depend_on_world_size():
     # the incumbent's jittered copies open the grid
     inc = comp[np.argmin(vals)]
     assert np.max(np.abs(full[:10] - inc)) < 0.01
+
+
+def test_shard_2d_covers_the_product():
+    for M, H, P, ph in [(1000, 20, 8, 2), (1000, 20, 8, 4), (77, 5, 4, 1), (50, 3, 6, 3)]:
+        seen = np.zeros((M, H), dtype=int)
+        for r in range(P):
+            (c0, c1), (h0, h1) = sd.shard_2d(M, H, P, r, ph)
+            seen[c0:c1, h0:h1] += 1
+        assert np.all(seen == 1)                     # every (candidate, draw) evaluated exactly once
+    with pytest.raises(ValueError):
+        sd.grid_2d(8, 3)
+
+
+def _worker_2d(rank, world, port, q):
+    import torch.distributed as tdist
+    from oracle import gp_ei_oracle as orc
+    from spearmint_amd.synthetic import synthetic_problem
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    comp, cand, vals, hypers = synthetic_problem(40, 301, 3, 6, 17)
+    (c0, c1), (h0, h1) = sd.shard_2d(301, 6, world, rank, 2)
+    ei = orc.ei_over_hypers(comp, cand[c0:c1], vals, hypers[h0:h1])       # this rank's block of overall_ei
+    idx, val, mean = sd.allreduce_ei_sums(np.sum(ei, axis=1), c0, 301, 6)
+    q.put((rank, idx, val, mean))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_2d_partition_allreduce_gloo_world4():
+    """draws x candidates over 4 ranks (2 x 2): one all-reduce(SUM) of the M-vector, every rank ends with the mean EI
+    of every candidate and the reference's argmax."""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from oracle import gp_ei_oracle as orc
+    from spearmint_amd.synthetic import synthetic_problem
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_2d, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    comp, cand, vals, hypers = synthetic_problem(40, 301, 3, 6, 17)
+    ref = np.mean(orc.ei_over_hypers(comp, cand, vals, hypers), axis=1)
+    for rank, idx, val, mean in res:
+        assert idx == int(np.argmax(ref))
+        # (the oracle's BLAS results depend on the column blocking at the 1e-12 level)
+        assert np.allclose(mean, ref, rtol=1e-9, atol=1e-300) and np.isclose(val, ref[idx], rtol=1e-9)
+    assert all(np.array_equal(res[0][3], r[3]) for r in res[1:])           # bit-identical on every rank

@@ -137,7 +137,7 @@ def test_bench_two_ranks_equals_one_rank_over_concatenated_candidates(eng):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c2", "--no-cpu-baseline",
-           "--extra-steps", "1", "--c4-candidates", "30000", "--c5-candidates", "20000"]
+           "--extra-steps", "1", "--c4-candidates", "30000", "--c5-candidates", "20000", "--hyper-shards", "2"]
     res = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=850)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     line = [l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1]
@@ -160,6 +160,10 @@ def test_bench_two_ranks_equals_one_rank_over_concatenated_candidates(eng):
             i1, v1, _, _ = eng.ei_grid(scomp, svals, rows, shyp)
         assert (out[name]["best_index"], out[name]["best_ei"]) == (i1, v1)
         assert out[name]["config"]["candidates_total"] == M and out["%s_value" % name] > 0
+    # the optional 2-D partition (here 2 draw shards x 1 candidate shard, one all-reduce of the EI sums): same winner,
+    # mean EI equal up to the order of the sum over draws
+    assert out["c4_2d"]["best_index"] == out["c4"]["best_index"]
+    assert abs(out["c4_2d"]["best_ei"] - out["c4"]["best_ei"]) <= 1e-13 * abs(out["c4"]["best_ei"])
 
 
 # ---- spx_ei_grad_batch: the refinement objective ---------------------------------------------------
