@@ -312,6 +312,9 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     const int jbeg = (MODE == 2) ? 0 : blockIdx.y * rows_per_wg;
     const int jend = (MODE == 2) ? Np : min(Np, jbeg + rows_per_wg);
     for (int j0 = jbeg + wave * 16; j0 < jend; j0 += 64) {
+        // tile-major output feeds the right-looking factorisation, which only ever reads the tiles on and below
+        // the diagonal: the 64 x 64 tiles above it are not computed
+        if (MODE == 3 && (j0 >> 6) < (c0 >> 6)) continue;
         d4 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
