@@ -484,7 +484,7 @@ __device__ __forceinline__ void store_tile(double* __restrict__ tile, const d4 (
 
 __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, double* __restrict__ Dinv,
                                                    int* __restrict__ info, double* __restrict__ rhs,
-                                                   double* __restrict__ diagL, int Np, int k)
+                                                   double* __restrict__ diagL, int Np, int k, int col_only)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;              // [64][LDP]  L_i,k-1 (or the right-hand-side rows' block k-1); then S
@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, d
     const int i = k + blockIdx.y;
     // this workgroup's tiles: block row i (or the right-hand-side rows), block columns j0 .. j1 - 1
     const int j0 = k + blockIdx.z * LEAN_CH;
-    const int j1 = min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
+    // col_only (lazy updates, odd k): only block column k takes step k-1 now; the columns to its right take the
+    // steps k-1 and k together in the next launch (k_lean_step2)
+    const int j1 = col_only ? j0 + 1 : min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
     if (j0 >= j1) return;
     double* Lh = Lt + (size_t)h * Np * Np;
     double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
@@ -542,16 +544,84 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, d
     }
 }
 
+// k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile in ONE pass -- the accumulator tiles
+// of a workgroup's chunk stay in registers across both steps, so the trailing matrix is read and written once
+// per two block columns instead of once per column (its traffic is what bounds the update beyond a few draws).
+// Same order of steps per tile, same MFMA chain: bit-identical factor.  The workgroup of the diagonal tile goes
+// on to factor it, as in k_lean_step.
+__global__ __launch_bounds__(256, 2) void k_lean_step2(double* __restrict__ Lt, double* __restrict__ Dinv,
+                                                    int* __restrict__ info, double* __restrict__ rhs,
+                                                    double* __restrict__ diagL, int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;              // [64][LDP]  row operand of the current step; then S
+    double* B = smem + NB * LDP;   // [64][LDP]  column operand; then XT
+    double* T16 = B + NB * LDP;    // [4][16][18]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x;
+    const int nblk = Np / NB;
+    const bool is_rhs = rhs && blockIdx.y == gridDim.y - 1;
+    const int i = k + blockIdx.y;
+    const int j0 = k + blockIdx.z * LEAN_CH;
+    const int j1 = min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
+    if (j0 >= j1) return;
+    const int nc = j1 - j0;
+    double* Lh = Lt + (size_t)h * Np * Np;
+    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;
+    d4 acc[LEAN_CH][4], ta[4], tb[4];
+#pragma unroll
+    for (int c = 0; c < LEAN_CH; ++c)
+        if (c < nc) load_tile(row + (size_t)(j0 + c) * LEAN_TILE, acc[c]);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p = k - 2 + pass;
+        load_tile(row + (size_t)p * LEAN_TILE, ta);
+        load_tile(Lh + ((size_t)j0 * nblk + p) * LEAN_TILE, tb);
+        acc_tile_to_lds(ta, A, wave, g, li);      // (the barrier that ended the previous pass freed A and B)
+#pragma unroll
+        for (int c = 0; c < LEAN_CH; ++c)
+            if (c < nc) {
+                acc_tile_to_lds(tb, B, wave, g, li);
+                __syncthreads();
+                if (c + 1 < nc) load_tile(Lh + ((size_t)(j0 + c + 1) * nblk + p) * LEAN_TILE, tb);
+                mma_tile_64(A, B, acc[c], wave, g, li, true);
+                __syncthreads();
+            }
+    }
+    if (!is_rhs && i == k && j0 == k) {
+        acc_tile_to_lds(acc[0], A, wave, g, li);
+        __syncthreads();
+        diag_block(A, B, T16, info + h, k * NB, nullptr, 0, Dinv + ((size_t)h * nblk + k) * NB * NB,
+                   diagL + (size_t)h * Np + (size_t)k * NB);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < LEAN_CH; ++c)
+        if (c < nc) store_tile(row + (size_t)(j0 + c) * LEAN_TILE, acc[c]);
+}
+
+// lazy = 1: updates are applied two steps at a time (k_lean_step2 at even k >= 2; at odd k only block column k is
+// brought up to date); lazy = 0: every launch applies one step to every remaining tile.
 void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int Np, int k,
-                      int nh)
+                      int nh, int lazy)
 {
     const int n = Np / NB - k;
     if (n <= 0) return;
     const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
+    if (lazy && k >= 2 && (k & 1) == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step2),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_lean_step2, dim3(nh, n + (rhs ? 1 : 0), (n + LEAN_CH - 1) / LEAN_CH), dim3(256), lds, s, Lt,
+                           Dinv, info, rhs, diagL, Np, k);
+        return;
+    }
+    const int col_only = (lazy && (k & 1)) ? 1 : 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const dim3 grid = (k == 0) ? dim3(nh, 1, 1) : dim3(nh, n + (rhs ? 1 : 0), (n + LEAN_CH - 1) / LEAN_CH);
-    hipLaunchKernelGGL(k_lean_step, grid, dim3(256), lds, s, Lt, Dinv, info, (k == 0) ? nullptr : rhs, diagL, Np, k);
+    const dim3 grid = (k == 0) ? dim3(nh, 1, 1)
+                               : dim3(nh, n + (rhs ? 1 : 0), col_only ? 1 : (n + LEAN_CH - 1) / LEAN_CH);
+    hipLaunchKernelGGL(k_lean_step, grid, dim3(256), lds, s, Lt, Dinv, info, (k == 0) ? nullptr : rhs, diagL, Np, k,
+                       col_only);
 }
 
 // L_ik = A_ik L_kk^-T for the tiles below the diagonal block of column k and for the right-hand-side

@@ -50,7 +50,7 @@ void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np,
 void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int k, int nh, double* rhs = nullptr);
 // log-likelihood path, tile-major storage (chol_kernels.hip)
 void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int Np, int k,
-                      int nh);
+                      int nh, int lazy);
 void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs, int Np, int k, int nh);
 void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh);
 void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int N,

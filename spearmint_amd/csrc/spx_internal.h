@@ -70,6 +70,7 @@ struct spx_handle {
     int64_t kst_budget = 512ll << 20;   // K(X*,X) staging buffer per stream (bytes)
     int nstreams = 1;
     int cov_kind = 0;                   // SPX_COVAR_* (option "covar"); SE = ARDSE kernels on unit length scales
+    int lean_lazy = -1;                 // option "lean_lazy": 0 / 1 / -1 = by batch size
     int gemm_variant = 0;               // predict-GEMM variant of THIS handle (option "gemm_waves"); 0 = production
     struct spx_multi* multi = nullptr;  // non-null: this handle fronts several per-GPU handles (spx_multi.hip)
     struct spx_comm* comm = nullptr;    // non-null: one-process-per-GPU communicator attached (spx_comm_attach)

@@ -339,6 +339,16 @@ def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
     for h in (0, 19, 39):
         ref = orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:])
         assert np.isclose(big[h], ref, rtol=1e-11)
+    # ... nor on whether the trailing updates are applied one or two block columns at a time (option lean_lazy;
+    # by default chosen from the batch's size)
+    try:
+        for lazy in (0, 1):
+            eng.set_option("lean_lazy", lazy)
+            for lo, hi in ((0, 1), (1, 6), (20, 40)):
+                eng.set_hypers(hypers[lo:hi])
+                assert np.array_equal(eng.gp_logprob(), big[lo:hi])
+    finally:
+        eng.set_option("lean_lazy", -1)
 
 
 # ---- pending experiments ("next" row 2): fantasies on the GPU --------------------------
