@@ -22,13 +22,14 @@
 // ---------------------------------------------------------------------------
 // x / ls, row norms.   One thread per (row, draw).
 //   xs[h][row][d]  = factor * (x[row][d] / ls[h][d])     (0 for pad rows / dims)
+//   xs2 (optional) = 2 * xs  (exact: the pre-doubled second operand of gp.py:50, same launch)
 //   sumsq[h][row]  = sum_d (x[row][d] / ls[h][d])^2
 // ---------------------------------------------------------------------------
 #define SR_DC 32   // feature columns per LDS pass
 __global__ __launch_bounds__(256) void k_scale_rows(
     const double* __restrict__ x, int64_t n, int64_t n_pad, int D, int Dp,
     const double* __restrict__ ls, int ls_stride, double factor,
-    double* __restrict__ xs, double* __restrict__ sumsq)
+    double* __restrict__ xs, double* __restrict__ sumsq, double* __restrict__ xs2)
 {
 #pragma clang fp contract(off)
     // 256 rows per workgroup, staged through LDS so that both the read of x (rows of D doubles)
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void k_scale_rows(
     const int64_t row = row0 + tid;
     const double* lsh = ls + (size_t)h * ls_stride;
     double* o = xs + ((size_t)h * n_pad + row0) * Dp;
+    double* o2 = xs2 ? xs2 + ((size_t)h * n_pad + row0) * Dp : nullptr;
     double acc = 0.0;
     for (int d0 = 0; d0 < Dp; d0 += SR_DC) {
         const int dc = (Dp - d0 < SR_DC) ? (Dp - d0) : SR_DC;                    // output columns
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void k_scale_rows(
         for (int e = tid; e < rows * dc; e += 256) {
             const int r = e / dc, c = e - r * dc;
             o[(size_t)r * Dp + d0 + c] = T[r][c];
+            if (o2) o2[(size_t)r * Dp + d0 + c] = 2.0 * T[r][c];
         }
         __syncthreads();
     }
@@ -75,11 +78,11 @@ __global__ __launch_bounds__(256) void k_scale_rows(
 
 void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp,
                        const double* ls, int ls_stride, int nh, double factor,
-                       double* xs, double* sumsq)
+                       double* xs, double* sumsq, double* xs2)
 {
     dim3 grid((unsigned)((n_pad + 255) / 256), nh);
     hipLaunchKernelGGL(k_scale_rows, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride,
-                       factor, xs, sumsq);
+                       factor, xs, sumsq, xs2);
 }
 
 // The epilogue below runs once per covariance entry (4e8 times per draw at C3).  What bounds

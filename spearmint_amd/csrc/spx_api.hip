@@ -310,9 +310,8 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     if (!lean) HIPCHK(hipMemsetAsync(h->WT.p, 0, nn * 8, s));
 
     const double* ls = h->hyp.d() + 3;
-    TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d()));
-    // second operand pre-multiplied by 2 (gp.py:50); the row norms it writes are identical
-    TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 2.0, h->X2s.d(), h->s1.d()));
+    // x / ls and, in the same launch, the second operand pre-multiplied by 2 (gp.py:50; exact)
+    TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d(), h->X2s.d()));
     // Blocked left-looking Cholesky for the EI path (many draws: every panel launch fills the chip).
     // The log-likelihood path (a handful of draws) runs the same 64x64 tiles right-looking, on a
     // tile-major copy of the matrix: one-step-deep launches instead of k sequential steps per tile, the
