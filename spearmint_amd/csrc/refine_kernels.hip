@@ -84,42 +84,51 @@ void launch_point_cov(hipStream_t s, const double* Xs, const double* s1, const d
                        kvec, dkdr2, N, Np, D, Dp, P, kind);
 }
 
-// out[h][p][i] = sum_{j <= i} WT_h[j][i] rhs[h][p][j]   (t = W k): one thread per row i, PB
-// right-hand sides per pass over W.  Each sum runs over j in increasing order.
+// out[h][p][i] = sum_{j <= i} WT_h[j][i] rhs[h][p][j]   (t = W k), PB right-hand sides per pass over W.
+// A workgroup owns 64 rows i; its four wavefronts split the j range of those rows four ways (wave w takes
+// j = w, w + 4, ...: a quarter of the serial depth each -- the loop is latency-bound, one dependent chain per
+// row), and the four partial sums of a row are added in the fixed order w = 0..3.  Each partial sum runs over
+// its j in increasing order, so a point's result does not depend on what else is in the batch.
 __global__ __launch_bounds__(256) void k_trimv_multi(const double* __restrict__ WT,
                                                      const double* __restrict__ rhs,
                                                      double* __restrict__ out, int Np, int P)
 {
     __shared__ double r[PB][256];
+    __shared__ double part[4][PB][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = blockIdx.y, p0 = blockIdx.z * PB;
     const int np = min(PB, P - p0);
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
     const double* Wh = WT + (size_t)h * Np * Np;
     const double* rh = rhs + ((size_t)h * P + p0) * Np;
     double acc[PB];
 #pragma unroll
     for (int q = 0; q < PB; ++q) acc[q] = 0.0;
-    const int jmax = blockIdx.x * 256 + 255;
+    const int jmax = blockIdx.x * 64 + 63;          // largest row of this workgroup
     for (int jb = 0; jb <= jmax; jb += 256) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PB; ++q)
             r[q][threadIdx.x] = (q < np && jb + threadIdx.x < Np) ? rh[(size_t)q * Np + jb + threadIdx.x] : 0.0;
         __syncthreads();
-        const int jn = (i < Np) ? min(256, i - jb + 1) : 0;
-        for (int t = 0; t < jn; ++t) {
+        const int jn = (i < Np) ? min(256, i - jb + 1) : 0;     // this row needs j = jb .. jb + jn - 1
+        for (int t = wave; t < jn; t += 4) {
             const double w = Wh[(size_t)(jb + t) * Np + i];
 #pragma unroll
             for (int q = 0; q < PB; ++q) acc[q] += w * r[q][t];
         }
     }
-    if (i < Np)
-        for (int q = 0; q < np; ++q) out[((size_t)h * P + p0 + q) * Np + i] = acc[q];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) part[wave][q][lane] = acc[q];
+    __syncthreads();
+    if (wave == 0 && i < Np)
+        for (int q = 0; q < np; ++q)
+            out[((size_t)h * P + p0 + q) * Np + i] = ((part[0][q][lane] + part[1][q][lane]) + part[2][q][lane]) + part[3][q][lane];
 }
 
 void launch_trimv_multi(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh, int P)
 {
-    hipLaunchKernelGGL(k_trimv_multi, dim3((Np + 255) / 256, nh, (P + PB - 1) / PB), dim3(256), 0, s, WT, rhs,
+    hipLaunchKernelGGL(k_trimv_multi, dim3((Np + 63) / 64, nh, (P + PB - 1) / PB), dim3(256), 0, s, WT, rhs,
                        out, Np, P);
 }
 
