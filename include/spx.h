@@ -209,7 +209,9 @@ const char* spx_timing_name(int i);
 #define SPX_COVAR_SE       3   /* gp.SE       (gp.py:87-93): ARDSE with the length scales ignored */
 /* options: "covar" (SPX_COVAR_*); tuning knobs "kstar_budget_bytes" (K(X*,X) staging buffer;
  * 0 = default), "streams" (1|2), "timing" (0|1), "gemm_waves" (predict-GEMM variant of THIS
- * handle; values the build does not contain are rejected with SPX_ERR_ARG).                    */
+ * handle; values the build does not contain are rejected with SPX_ERR_ARG), "lean_lazy"
+ * (log-likelihood path: trailing updates one (0) or two (1) block columns at a time, -1 = chosen
+ * from the batch size; results are bit-identical either way).                                  */
 int spx_set_option(spx_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -14,9 +14,11 @@
 //                 one wavefront on the matrix pipe (factor16_mfma: a rank-1 MFMA
 //                 per pivot), sub-panel and trailing updates by MFMA; the inverse
 //                 of the block by block forward substitution (MFMA).
-//   k_lean_step   (log-likelihood path) one right-looking update step for every
-//                 trailing tile, the diagonal block factored by the workgroup
-//                 that owns it.
+//   k_lean_step   (log-likelihood path, tile-major storage) one right-looking
+//                 update step for every trailing tile, the diagonal block factored
+//                 by the workgroup that owns it; k_lean_step2: two steps per pass
+//                 for batches that outgrow the Infinity Cache; k_lean_trsm: the
+//                 panel's triangular solve.
 //   k_chol_panel  1 workgroup / (row block > k, draw):
 //                 L_rk = (K_rk - L_r,:k L_k,:k^T) L_kk^-T          (MFMA)
 // k_trinv: W = L^-1 by block columns (one launch), stored transposed
