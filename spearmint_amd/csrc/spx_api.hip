@@ -434,20 +434,19 @@ int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, in
 static void plan_chunks(const spx_handle* h, int64_t* Mc, int* Hb)
 {
     const int64_t Mp = round_up(h->M, SPX_BN);
-    int64_t mc = h->kst_budget / (8ll * h->Np);
-    mc = mc / SPX_BN * SPX_BN;
-    if (mc < SPX_BN) mc = SPX_BN;
-    if (mc > Mp) mc = Mp;
+    int64_t mc_budget = h->kst_budget / (8ll * h->Np) / SPX_BN * SPX_BN;   // what the staging buffer holds of one draw
+    if (mc_budget < SPX_BN) mc_budget = SPX_BN;
+    int64_t mc = mc_budget < Mp ? mc_budget : Mp;
     // equal-sized chunks (no tiny, inefficient last launch) ...
-    const int64_t mc_max = mc;
     const int64_t nchunks = (Mp + mc - 1) / mc;
     mc = round_up((Mp + nchunks - 1) / nchunks, SPX_BN);
-    // ... of a whole number of candidate tiles per XCD: the predict GEMM deals the 128-candidate tiles of a launch
-    // round-robin to the 8 XCDs, and a launch with 245 tiles runs as long as one with 248 (measured at C3: 7 chunks
-    // of 224 tiles 268 ms per step, 6 of 261 or 5 of 313 tiles 273 ms)
-    if (mc >= 8 * SPX_BN) {
+    // ... of a whole number of candidate tiles per XCD when there are several: the predict GEMM deals the
+    // 128-candidate tiles of a launch round-robin to the 8 XCDs, and a launch with 245 tiles runs as long as one
+    // with 248 (measured at C3: 7 chunks of 224 tiles 268 ms per step, 6 of 261 or 5 of 313 tiles 273 ms)
+    if (nchunks > 1) {
         const int64_t up = round_up(mc, 8 * SPX_BN);
-        mc = (up <= mc_max) ? up : mc / (8 * SPX_BN) * (8 * SPX_BN);
+        if (up <= mc_budget) mc = up;
+        else if (mc >= 16 * SPX_BN) mc = mc / (8 * SPX_BN) * (8 * SPX_BN);
     }
     int64_t hb = h->kst_budget / (8ll * h->Np * mc);
     if (hb < 1) hb = 1;
