@@ -10,7 +10,6 @@ import numpy.random as npr
 
 from .. import hostgp
 from .. import util
-from ..helpers import log
 from ._base import GPEIBase
 
 

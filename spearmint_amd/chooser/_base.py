@@ -23,7 +23,6 @@ from __future__ import absolute_import, print_function
 import os
 
 import numpy as np
-import numpy.random as npr
 
 from .. import hostgp
 from .. import util

@@ -23,7 +23,7 @@ import pytest
 
 import bench
 from oracle import gp_ei_oracle as orc
-from spearmint_amd.engine import Engine, FLAG_PER_SEC, MultiEngine
+from spearmint_amd.engine import Engine, MultiEngine
 from spearmint_amd.synthetic import synthetic_problem
 
 pytestmark = pytest.mark.gpu

@@ -57,7 +57,6 @@ def test_pending_matches_reference(golden_dir):
 def test_fantasy_half_of_pending_branch(golden_dir):
     """compute_ei_fantasies (what the GPU path mirrors) + the host fantasy draw
     reproduce the reference's pending branch."""
-    import scipy.linalg as spla
     from spearmint_amd import hostgp
     g = _load(golden_dir, "ei_pending.npz")
     comp, pend, cand, vals = g["comp"], g["pend"], g["cand"], g["vals"]
