@@ -95,8 +95,11 @@ class GPEIBase(object):
         return self._eng
 
     def __getstate__(self):
+        # pickling (the reference ships copy.copy(self) to multiprocessing workers, GPEIOptChooser.py:274-280)
+        # drops the handle.  os.fork() does NOT pickle: a forked child inherits `_eng` as it is, and Engine
+        # itself refuses calls from a pid other than its creator's (engine.py: Engine._h).
         d = dict(self.__dict__)
-        d["_eng"] = None          # ctypes handles / HIP contexts do not survive pickling or fork
+        d["_eng"] = None
         return d
 
     # -- persistent state -------------------------------------------------------

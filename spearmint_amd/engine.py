@@ -136,20 +136,39 @@ class Engine(object):
 
     def __init__(self, device=0, lib=None, devices=None):
         self._lib = load_library(lib)
-        self._h = _vp()
+        self._handle = _vp()
+        # The handle, its HIP streams and device buffers belong to the process that created them.  The
+        # reference's drivers fork AFTER the chooser has run (job processes from the main loop,
+        # spearmint/driver/local.py:9-44; the status web server, main.py:126-141): a child inherits this
+        # object but not a usable HIP context, so every call from another pid is refused (`_h` below) and
+        # such a copy never destroys the parent's handle.
+        self._pid = os.getpid()
         if devices is not None:
             devs = [int(d) for d in devices]
             if not devs:
                 raise ValueError("Engine needs at least one device")
             arr = (ctypes.c_int32 * len(devs))(*devs)
-            self._check(self._lib.spx_create_multi(arr, len(devs), ctypes.byref(self._h)))
+            self._check(self._lib.spx_create_multi(arr, len(devs), ctypes.byref(self._handle)))
             self.devices = devs
             self.device = devs[0]
         else:
-            self._check(self._lib.spx_create(int(device), ctypes.byref(self._h)))
+            self._check(self._lib.spx_create(int(device), ctypes.byref(self._handle)))
             self.device = int(device)
             self.devices = [self.device]
         self.N = self.M = self.D = self.H = 0
+
+    @property
+    def _h(self):
+        """The C handle -- only in the process that created it."""
+        if self._pid != os.getpid():
+            raise SpxError("this Engine's HIP context belongs to pid %d and is not usable in pid %d (a forked "
+                           "child): create a new Engine in this process" % (self._pid, os.getpid()))
+        if self._handle is None or not self._handle:
+            raise SpxError("Engine is closed")
+        return self._handle
+
+    def owned_by_this_process(self):
+        return self._pid == os.getpid()
 
     def comm_unique_id(self):
         """128 bytes identifying a new RCCL communicator (call on one rank, ship to the others)."""
@@ -184,9 +203,11 @@ class Engine(object):
         raise SpxError(msg)
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h:
-            self._lib.spx_destroy(self._h)
-            self._h = None
+        h = self.__dict__.get("_handle")
+        if h is not None and h:
+            if self.__dict__.get("_pid") == os.getpid():   # a forked copy must leave the parent's handle alone
+                self._lib.spx_destroy(h)
+            self._handle = None
 
     def __del__(self):
         try:

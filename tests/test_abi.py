@@ -116,3 +116,33 @@ def test_header_is_plain_c(tmp_path):
                    "}\n")
     subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
                            "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def _child_uses_inherited_engine(eng, q):
+    try:
+        eng.set_option("timing", 0)
+        q.put("no error")
+    except engine.SpxError as e:
+        q.put("SpxError: %s" % e)
+    # interpreter teardown now runs Engine.__del__ on the inherited copy: it must not call spx_destroy
+
+
+def test_engine_refuses_calls_from_a_forked_child(lib):
+    """The drivers fork after the chooser has created its engine (spearmint/driver/local.py:9-44): the child's
+    copy of the handle must be unusable -- and harmless -- there, and the parent's must keep working."""
+    import multiprocessing
+    eng = engine.Engine(0)
+    ctx = multiprocessing.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_child_uses_inherited_engine, args=(eng, q))
+    p.start()
+    msg = q.get(timeout=60)
+    p.join(60)
+    assert p.exitcode == 0
+    assert msg.startswith("SpxError") and "pid %d" % os.getpid() in msg
+    assert eng.owned_by_this_process()
+    eng.set_option("timing", 0)            # the parent's handle is alive: the child did not destroy it
+    eng.close()
+    with pytest.raises(engine.SpxError):
+        eng.set_option("timing", 0)        # closed
+    eng.close()                            # idempotent
