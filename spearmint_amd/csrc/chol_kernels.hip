@@ -103,12 +103,14 @@ __device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B
 // mailbox, per pivot or per four pivots, the inverse wave spinning on a sequence word -- was measured:
 // the factor wave alone runs 300 cycles per pivot next to its busy neighbours, and the inverse wave
 // trails by ~1.1k cycles, 5.9k per sub-block either way against 5.85k for this single-wave form.)
-__device__ __forceinline__ void factor16_mfma(d4& C, d4& X, d4& U, int lane, int& bad, int pivot_base)
+__device__ __forceinline__ void factor16_mfma(d4& C, d4& Xo, d4& U, int lane, int& bad, int pivot_base)
 {
     const int c = lane & 15, q = lane >> 4;
+    d4 X;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         X[r] = (q + 4 * r == c) ? 1.0 : 0.0;
+        Xo[r] = 0.0;
         U[r] = 0.0;
     }
 #pragma unroll
@@ -130,7 +132,9 @@ __device__ __forceinline__ void factor16_mfma(d4& C, d4& X, d4& U, int lane, int
         const double aX = (grp && c > j) ? -lcol : 0.0;
         C = MFMA_F64(-b, b, C);
         X = MFMA_F64(aX, bX, X);
-        X[rj] = grp ? xs : X[rj];
+        // row j of X is final: it is collected in Xo, not written back into the accumulator (a VALU write to an
+        // MFMA destination right behind the MFMA stalls the in-order wave: 328 -> 316 cycles per pivot)
+        Xo[rj] = grp ? xs : Xo[rj];
         // the diagonal entry sqrt(d) to ~0.5 ulp (off the critical path)
         double sd = d * rinv;
         sd = fma(fma(-sd, sd, d), 0.5 * rinv, sd);
@@ -158,8 +162,7 @@ __device__ __forceinline__ void factor16_mfma(d4& C, d4& X, d4& U, int lane, int
 // first product is itself in B-operand layout for the second.
 #define DIAG_T16_DOUBLES (4 * 16 * 18)
 
-__device__ __forceinline__ void inv_block_row(const double* S, double* XT, const double* T16, int i, int j,
-                                              int g, int li)
+__device__ __forceinline__ d4 inv_partial(const double* S, const double* XT, int i, int j, int g, int li)
 {
     d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};
     for (int pb = j; pb < i; ++pb) {
@@ -170,12 +173,22 @@ __device__ __forceinline__ void inv_block_row(const double* S, double* XT, const
             t4 = MFMA_F64(av, bv, t4);
         }
     }
+    return t4;
+}
+// X_ij = -Linv16_i t4: into XT (transposed, for the products of the rows below) and straight to Dk (row-major
+// [64][64]) from the registers of the wave that computed it
+__device__ __forceinline__ void inv_finish(const d4& t4, double* XT, const double* T16, double* __restrict__ Dk,
+                                           int i, int j, int g, int li)
+{
     d4 o4 = (d4){0.0, 0.0, 0.0, 0.0};
     const double* Ti = T16 + i * 16 * 18;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) o4 = MFMA_F64(-Ti[li * 18 + 4 * ks + g], t4[ks], o4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
+    for (int r = 0; r < 4; ++r) {
+        XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
+        Dk[(16 * i + g + 4 * r) * NB + 16 * j + li] = o4[r];
+    }
 }
 
 // S(ti,tj) -= P_ti P_tj^T with the sub-panel tiles of column b
@@ -207,7 +220,19 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     int bad = 0;
+    d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};     // waves 1-3: inner sum of the last row of the inverse (column wave - 1)
     STAMP(0);
+    if (wave > 0) {
+        // The inverse goes to global memory block by block from the registers of the wave that computes it; the
+        // blocks above the block diagonal are zero: (0,1) (0,2) | (0,3) (1,2) | (1,3) (2,3) for waves 1 | 2 | 3.
+        const int zi0 = (wave == 3) ? 1 : 0, zj0 = (wave == 1) ? 1 : 3;
+        const int zi1 = (wave == 1) ? 0 : (wave == 2 ? 1 : 2), zj1 = (wave == 3) ? 3 : 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Dk[(16 * zi0 + g + 4 * r) * NB + 16 * zj0 + li] = 0.0;
+            Dk[(16 * zi1 + g + 4 * r) * NB + 16 * zj1 + li] = 0.0;
+        }
+    }
     for (int b = 0; b < 4; ++b) {
         const int b0 = 16 * b;
         double* Tb = T16 + b * 16 * 18;
@@ -232,8 +257,11 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                     if (ti == b && tj == b) continue;
                     if ((idx++ % 3) == wave - 1) trail_tile(S, ti, tj, b0 - 16, g, li);
                 }
-            // row b-1 of the inverse: blocks j = 0 .. b-2
-            for (int j = wave - 1; j < b - 1; j += 3) inv_block_row(S, XT, T16, b - 1, j, g, li);
+            // row b-1 of the inverse: wave j + 1 owns block column j (all X_pj of a column come from one wave)
+            if (wave - 1 < b - 1) inv_finish(inv_partial(S, XT, b - 1, wave - 1, g, li), XT, T16, Dk, b - 1, wave - 1, g, li);
+            // while wave 0 factors the last sub-block: the inner sum of the LAST row, so that only the product
+            // with Linv16_3 is left behind the last pivot (reads this wave's own XT stores: same wave, in order)
+            if (b == 3) t4 = inv_partial(S, XT, 3, wave - 1, g, li);
         }
         STAMP(1 + 4 * b);
         __syncthreads();
@@ -251,6 +279,11 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + b0 + li] = c4[r];
+            } else if (wave == 3) {
+                // (wave 3 never has a sub-panel tile) the inverse's diagonal block, from T16 to global memory -- not by
+                // wave 0 from its registers: four global stores in the critical wave cost ~200 cycles per round
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Dk[(b0 + g + 4 * r) * NB + b0 + li] = Tb[(g + 4 * r) * 18 + li];
             }
         }
         if (b < 3) __syncthreads();   // round 3 has no sub-panel: nothing was written
@@ -262,20 +295,15 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
     if (wave == 0 && lane == 0 && bad) {
         if (*info_h == 0) *info_h = bad;
     }
-    // last row of the inverse (row 2 is complete: its two blocks were built in phase 1 of round 3)
-    if (wave < 3) inv_block_row(S, XT, T16, 3, wave, g, li);
-    __syncthreads();
+    // last row of the inverse: one product with Linv16_3 per block (rows 0-2 went out as they were built)
+    if (wave > 0) inv_finish(t4, XT, T16, Dk, 3, wave - 1, g, li);
     STAMP(17);
-    // write L_kk (upper part zero) and its inverse, 16 bytes per lane; the log-likelihood path only
-    // needs the diagonal of L_kk (diag_out) besides the inverse
+    // L_kk (upper part zero), 16 bytes per lane (S is complete since the last barrier); the log-likelihood path
+    // only needs its diagonal (diag_out)
     if (diag_out && threadIdx.x < NB) diag_out[threadIdx.x] = S[threadIdx.x * LDP + threadIdx.x];
-    for (int idx = threadIdx.x; idx < NB * NB / 2; idx += 256) {
-        const int row = idx >> 5, col = (idx & 31) * 2;
-        d2 xv;
-        xv[0] = (col <= row) ? XT[col * LDP + row] : 0.0;
-        xv[1] = (col + 1 <= row) ? XT[(col + 1) * LDP + row] : 0.0;
-        *reinterpret_cast<d2*>(Dk + row * NB + col) = xv;
-        if (Lkk) {
+    if (Lkk) {
+        for (int idx = threadIdx.x; idx < NB * NB / 2; idx += 256) {
+            const int row = idx >> 5, col = (idx & 31) * 2;
             d2 lv;
             lv[0] = (col <= row) ? S[row * LDP + col] : 0.0;
             lv[1] = (col + 1 <= row) ? S[row * LDP + col + 1] : 0.0;
@@ -504,9 +532,10 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, d
     const int i = k + blockIdx.y;
     // this workgroup's tiles: block row i (or the right-hand-side rows), block columns j0 .. j1 - 1
     const int j0 = k + blockIdx.z * LEAN_CH;
-    // col_only (lazy updates, odd k): only block column k takes step k-1 now; the columns to its right take the
-    // steps k-1 and k together in the next launch (k_lean_step2)
-    const int j1 = col_only ? j0 + 1 : min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
+    // col_only (lazy updates, odd k): only block columns k and k + 1 take step k-1 now -- column k is then complete
+    // and column k + 1 will need just ONE more step before its diagonal block is factored, so no diagonal block ever
+    // waits for two -- and the columns to their right take the steps k-1 and k together in the next launch (k_lean_step2)
+    const int j1 = min(col_only ? j0 + 2 : j0 + LEAN_CH, is_rhs ? nblk : i + 1);
     if (j0 >= j1) return;
     double* Lh = Lt + (size_t)h * Np * Np;
     double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
@@ -546,7 +575,8 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, d
     }
 }
 
-// k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile in ONE pass -- the accumulator tiles
+// k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile right of block column k (which needs
+// only step k-1: see col_only in k_lean_step) in ONE pass -- the accumulator tiles
 // of a workgroup's chunk stay in registers across both steps, so the trailing matrix is read and written once
 // per two block columns instead of once per column (its traffic is what bounds the update beyond a few draws).
 // Same order of steps per tile, same MFMA chain: bit-identical factor.  The workgroup of the diagonal tile goes
@@ -577,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_step2(double* __restrict__ Lt, 
         if (c < nc) load_tile(row + (size_t)(j0 + c) * LEAN_TILE, acc[c]);
     for (int pass = 0; pass < 2; ++pass) {
         const int p = k - 2 + pass;
+        if (pass == 0 && j0 == k && nc == 1) continue;   // (uniform) a chunk that is block column k alone: step k-1 only
         load_tile(row + (size_t)p * LEAN_TILE, ta);
         load_tile(Lh + ((size_t)j0 * nblk + p) * LEAN_TILE, tb);
         acc_tile_to_lds(ta, A, wave, g, li);      // (the barrier that ended the previous pass freed A and B)
@@ -586,7 +617,8 @@ __global__ __launch_bounds__(256, 2) void k_lean_step2(double* __restrict__ Lt, 
                 acc_tile_to_lds(tb, B, wave, g, li);
                 __syncthreads();
                 if (c + 1 < nc) load_tile(Lh + ((size_t)(j0 + c + 1) * nblk + p) * LEAN_TILE, tb);
-                mma_tile_64(A, B, acc[c], wave, g, li, true);
+                // block column k already took step k-2 in the previous (odd) launch
+                if (!(pass == 0 && j0 + c == k)) mma_tile_64(A, B, acc[c], wave, g, li, true);
                 __syncthreads();
             }
     }
@@ -600,6 +632,179 @@ __global__ __launch_bounds__(256, 2) void k_lean_step2(double* __restrict__ Lt, 
 #pragma unroll
     for (int c = 0; c < LEAN_CH; ++c)
         if (c < nc) store_tile(row + (size_t)(j0 + c) * LEAN_TILE, acc[c]);
+}
+
+// k_lean_fused: ONE launch per block column (small batches; the two-launch form above stays for lazy updates).
+// Launch k applies update step k-1 like k_lean_step, but no launch has solved the panel of column k-1: every
+// workgroup forms the operands it needs itself from the RAW panel tiles R_i,k-1 (complete but not yet multiplied
+// by L_k-1,k-1^-T) and the inverse of the diagonal block that launch k-1 left in Dinv,
+//     L_i,k-1 = R_i,k-1 Dinv_k-1^T ,
+// -- the same 64-deep MFMA chain per element as k_lean_trsm, so the factor keeps its bits.  What that buys: the
+// dependent chain of a block column is  launch -> (this tile's two operands) -> update -> diagonal block  instead
+// of  launch -> update -> diagonal block -> launch -> panel solve;  what it costs: a workgroup that walks nc tiles
+// of a block row multiplies 1 + 2 nc tile products instead of nc, which the matrix pipes have to spare while the
+// diagonal workgroup runs its pivots (one draw) and while the tile traffic binds (several draws).
+//   row operand:  each wave needs only ITS 16 rows of L_i,k-1 as MFMA A fragments.  It computes their transpose,
+//       (L_i^T)(16 b + n', 16 w + i) = sum_q Dinv[16 b + n'][q] R_i[16 w + i][q] ,
+//     whose accumulator layout (reg r of lane (c, q) = L_i[16 w + c][16 b + q + 4 r]) IS the A fragment of k-step
+//     16 b + 4 r: the row operand never goes through LDS, and two LDS tiles (Dinv; the column operand) keep two
+//     workgroups per CU.
+//   column operand: L_j,k-1 = R_j Dinv^T through LDS (every wave reads all of it).
+// The right-hand-side rows' solved blocks -- y, what the log-likelihood needs -- go to ybuf[h][Np] (row 0 of the
+// block): block k-1 in launch k, so the last launch is k = nblk with the right-hand-side workgroups only.
+__global__ __launch_bounds__(256, 2) void k_lean_fused(double* __restrict__ Lt, double* __restrict__ Dinv,
+                                                    int* __restrict__ info, double* __restrict__ rhs,
+                                                    double* __restrict__ diagL, double* __restrict__ ybuf,
+                                                    int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Dv = smem;              // [64][LDP]  Dinv_k-1 (row-major); the diagonal workgroup's XT afterwards
+    double* Bb = smem + NB * LDP;   // [64][LDP]  raw panel tile, then the column operand L_j,k-1; then S
+    double* T16 = Bb + NB * LDP;    // [4][16][18]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x;       // draws on x: the diagonal workgroups of all draws are dispatched first
+    const int nblk = Np / NB;
+    const bool is_rhs = rhs && blockIdx.y == gridDim.y - 1;
+    const int i = k + blockIdx.y;
+    const int j0 = k + blockIdx.z * LEAN_CH;
+    const int j1 = min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
+    const bool want_y = is_rhs && blockIdx.z == 0;          // this workgroup publishes y block k-1
+    if (j0 >= j1 && !want_y) return;
+    double* Lh = Lt + (size_t)h * Np * Np;
+    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
+    d4 acc[4];
+    if (k == 0) {                   // nothing to apply: the diagonal block as cov left it
+        load_tile(row, acc);
+        acc_tile_to_lds(acc, Bb, wave, g, li);
+        __syncthreads();
+        diag_block(Bb, Dv, T16, info + h, 0, nullptr, 0, Dinv + (size_t)h * nblk * NB * NB, diagL + (size_t)h * Np);
+        return;
+    }
+    const int kp = k - 1;
+    d4 accn[4], rj[4], aT[4];
+    {
+        d4 ri[4];
+        load_tile(row + (size_t)kp * LEAN_TILE, ri);
+        if (j0 < j1) {
+            load_tile(row + (size_t)j0 * LEAN_TILE, accn);
+            load_tile(Lh + ((size_t)j0 * nblk + kp) * LEAN_TILE, rj);
+        }
+        tile_to_lds(Dinv + ((size_t)h * nblk + kp) * NB * NB, NB, Dv);
+        acc_tile_to_lds(ri, Bb, wave, g, li);
+    }
+    __syncthreads();
+    // this wave's rows of the row operand, transposed: aT[b][r] = L_i[16 wave + li][16 b + g + 4 r]
+#pragma unroll
+    for (int b = 0; b < 4; ++b) aT[b] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        const double bv = Bb[(16 * wave + li) * LDP + k0 + g];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) aT[b] = MFMA_F64(Dv[(16 * b + li) * LDP + k0 + g], bv, aT[b]);
+    }
+    if (want_y && wave == 0 && li == 0) {      // row 0 of the right-hand-side block: y[64 (k-1) + 16 b + g + 4 r]
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ybuf[(size_t)h * Np + (size_t)kp * NB + 16 * b + g + 4 * r] = aT[b][r];
+    }
+    for (int j = j0; j < j1; ++j) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = accn[nt];
+        const bool same = (!is_rhs && j == i);      // the column operand is the row operand (diagonal tile)
+        d4 lj[4];
+        __syncthreads();                             // every wave is done with Bb (row operand / previous tile)
+        if (!same) acc_tile_to_lds(rj, Bb, wave, g, li);
+        if (j + 1 < j1) {                            // the next tile's panel tile and accumulator fly meanwhile
+            load_tile(Lh + ((size_t)(j + 1) * nblk + kp) * LEAN_TILE, rj);
+            load_tile(row + (size_t)(j + 1) * LEAN_TILE, accn);
+        }
+        if (!same) {
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) lj[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+            mma_tile_64(Bb, Dv, lj, wave, g, li, false);     // L_j rows 16 wave .. : sum_q R_j[.][q] Dinv[n][q]
+            __syncthreads();
+            acc_tile_to_lds(lj, Bb, wave, g, li);
+            __syncthreads();
+        } else {
+            // L_i itself is the column operand: Bb[16 wave + li][16 b + g + 4 r] = aT[b][r]
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Bb[(16 * wave + li) * LDP + 16 * b + g + 4 * r] = aT[b][r];
+            __syncthreads();
+        }
+        // acc -= L_i L_j^T, k-steps in the order 0, 4, ..., 60 (k0 = 16 b + 4 r): the chain of mma_tile_64
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double a = -aT[b][r];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt] = MFMA_F64(a, Bb[(16 * nt + li) * LDP + 16 * b + 4 * r + g], acc[nt]);
+            }
+        if (same && i == k) {
+            // the serial part of the factorisation (this is the only tile of this workgroup)
+            __syncthreads();           // every wave is done reading Bb
+            acc_tile_to_lds(acc, Bb, wave, g, li);
+            __syncthreads();
+            diag_block(Bb, Dv, T16, info + h, k * NB, nullptr, 0, Dinv + ((size_t)h * nblk + k) * NB * NB,
+                       diagL + (size_t)h * Np + (size_t)k * NB);
+            return;
+        }
+        store_tile(row + (size_t)j * LEAN_TILE, acc);
+    }
+}
+
+void launch_lean_fused(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, double* ybuf,
+                       int Np, int k, int nh)
+{
+    const int n = Np / NB - k;                 // block rows k .. nblk-1 still to update (0: only the y block is left)
+    if (n < 0) return;
+    const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_fused),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const dim3 grid = (k == 0) ? dim3(nh, 1, 1)
+                               : dim3(nh, n + 1, n > 0 ? (n + LEAN_CH - 1) / LEAN_CH : 1);
+    hipLaunchKernelGGL(k_lean_fused, grid, dim3(256), lds, s, Lt, Dinv, info, (k == 0) ? nullptr : rhs, diagL, ybuf,
+                       Np, k);
+}
+
+// lp from y in plain storage (k_lean_fused's ybuf) and the diagonal the diagonal blocks left in diagL
+__global__ __launch_bounds__(256) void k_lean_logprob_y(const double* __restrict__ diagL,
+                                                        const double* __restrict__ ybuf,
+                                                        const int* __restrict__ info,
+                                                        double* __restrict__ out, int N, int Np)
+{
+    __shared__ double red[2][256];
+    const int h = blockIdx.x;
+    double sl = 0.0, sq = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        sl += log(diagL[(size_t)h * Np + i]);
+        const double gi = ybuf[(size_t)h * Np + i];
+        sq += gi * gi;
+    }
+    red[0][threadIdx.x] = sl;
+    red[1][threadIdx.x] = sq;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[h] = info[h] ? -__builtin_inf() : (-red[0][0] - 0.5 * red[1][0]);
+}
+
+void launch_lean_logprob_y(hipStream_t s, const double* diagL, const double* ybuf, const int* info, double* out, int N,
+                           int Np, int nh)
+{
+    hipLaunchKernelGGL(k_lean_logprob_y, dim3(nh), dim3(256), 0, s, diagL, ybuf, info, out, N, Np);
 }
 
 // lazy = 1: updates are applied two steps at a time (k_lean_step2 at even k >= 2; at odd k only block column k is

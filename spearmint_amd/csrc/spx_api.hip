@@ -136,7 +136,7 @@ void spx_destroy(spx_handle* h)
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
                           &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
-                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL,
+                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ybuf,
                           &h->alphaS, &h->pt_u, &h->rec_send, &h->rec_recv, &h->rec_out};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -172,6 +172,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_lazy")) {   // log-likelihood path: trailing updates two steps at a time (1), one (0), by size (-1, default)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "lean_fused")) {  // log-likelihood path: one launch per block column (1), step + panel solve (0), by size (-1, default)
+        h->lean_fused = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
     if (!strcmp(name, "streams")) {  // 1 = everything on one stream (default), 2 = alternate EI work items
@@ -337,8 +341,20 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     // batch no longer fit the 256 MB Infinity Cache (measured: N=2048 from ~20 draws, N=4096 from 6; -3 ... -16 %),
     // and costs 5-10 % below that.  Same factor either way, bit for bit.
     const int lazy = h->lean_lazy >= 0 ? h->lean_lazy : ((double)nh * Np * Np * 4.0 > 300e6 ? 1 : 0);
-    for (int k = 0; k < nblk; ++k) {
-        if (rl) {
+    // One launch per block column (k_lean_fused: every workgroup forms the panel operands it needs itself) unless the
+    // batch is large enough for the lazy two-column updates; same factor, bit for bit.
+    // Measured (scripts/time_lean.py): the fused form wins where the launch count dominates (N <= 256: 0.178 vs 0.199 ms of
+    // kernels per call) and loses from N = 1024 on (one draw at N = 2048: 30.7 vs 28.1 us per block column; 8 draws 1.80
+    // vs 1.33 ms) -- its MFMA-heavy workgroups share SIMDs with the wave that runs the pivots -- so by default it is
+    // chosen by size (option lean_fused = -1); 0 / 1 force either form.
+    const int want_fused = h->lean_fused >= 0 ? h->lean_fused : (nblk <= 4 ? 1 : 0);
+    const int fused = (rl && !lazy && want_fused) ? 1 : 0;
+    h->lean_y = fused != 0;
+    if (fused && (rc = h->ybuf.reserve((size_t)nh * Np * 8))) return rc;
+    for (int k = 0; k < nblk + fused; ++k) {
+        if (fused) {
+            TIMED(ST_CHOL_DIAG, launch_lean_fused(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), h->ybuf.d(), Np, k, nh));
+        } else if (rl) {
             TIMED(ST_CHOL_DIAG, launch_lean_step(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), Np, k, nh, lazy));
             TIMED(ST_CHOL_PANEL, launch_lean_trsm(s, h->Lm.d(), h->Dinv.d(), rhs, Np, k, nh));
         } else {
@@ -738,7 +754,9 @@ int spx_gp_logprob(spx_handle* h, double* out)
     int rc = do_factor(h, true, true);   // K(X,X), Cholesky, forward solve -- no inverse
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
-    if (h->lean_tiled)
+    if (h->lean_tiled && h->lean_y)
+        launch_lean_logprob_y(h->stream, h->diagL.d(), h->ybuf.d(), (const int*)h->info.p, h->lp.d(), (int)h->N, h->Np, h->H);
+    else if (h->lean_tiled)
         launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, h->lp.d(), (int)h->N, h->Np, h->H);
     else
         launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);
