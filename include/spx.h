@@ -85,6 +85,23 @@ int  spx_multi_query(spx_handle* h, int32_t* n_dev, int32_t* transport, int32_t*
 #define SPX_COMM_ID_BYTES 128
 int  spx_comm_unique_id(char* id_out /* SPX_COMM_ID_BYTES */);
 int  spx_comm_attach(spx_handle* h, const char* id, int32_t nranks, int32_t rank);
+/* Optional 2-D partition, "hypers x candidates" (SURVEY.md 8(e)): P = hyper_shards x P_c devices / ranks, device
+ * r = rc * hyper_shards + rh evaluates the draws of hyper shard rh for the candidates of shard rc, and the path's
+ * single collective becomes ONE ncclAllReduce(SUM) of the zero-padded M-vector of per-candidate EI sums on the
+ * handle's stream (8 M bytes; the sums over a device's own draws are formed on the device in numpy's order), after
+ * which every device divides by the number of draws and takes numpy's argmax over ALL candidates: no per-draw EI
+ * leaves the device, no host-side reduction.  Each device then factors H / hyper_shards covariances instead of H.
+ * The sum over draws is "local sums, then the reduction tree", so means agree with the candidates-only scheme to
+ * ~1e-16 relative (near-ties may resolve differently): that scheme stays the default.
+ *   multi-device handle: spx_set_partition(h, hyper_shards, 0, 0) -- hyper_shards must divide n_dev; the library
+ *     shards draws and candidates itself on the following spx_set_hypers / spx_set_candidates (call it first).
+ *     spx_set_fantasies and spx_ei_grad_batch are not available with hyper_shards > 1.
+ *   one process per GPU (spx_comm_attach): the caller sets ITS draw shard (spx_set_hypers) and candidate shard
+ *     (spx_set_candidates with index_base) and passes the totals; M_total > 0 switches the collective of spx_ei_run
+ *     from the all-gather of records to the all-reduce of sums (hyper_shards = 1 is allowed: candidates only, but
+ *     every rank ends up with the whole mean vector); spx_get_ei_mean then returns the global means of the handle's
+ *     own candidates.  M_total = 0 switches back.                                                              */
+int  spx_set_partition(spx_handle* h, int32_t hyper_shards, int64_t M_total, int32_t H_total);
 void spx_destroy(spx_handle* h);
 const char* spx_last_error(void);
 int  spx_version(void);

@@ -103,6 +103,8 @@ void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part
                         int64_t M, int64_t Mp, int h0);
 void launch_mean_over_draws(hipStream_t s, const double* ei_draw, double* ei_mean, int64_t M,
                             int64_t Mp, int H);
+void launch_sum_over_draws(hipStream_t s, const double* ei_draw, double* out, int64_t M, int64_t Mp, int H);
+void launch_div_scalar(hipStream_t s, double* v, int64_t n, double denom);
 void launch_argmax(hipStream_t s, const double* v, int64_t M, double* blk_val, int64_t* blk_idx,
                    double* out_val, int64_t* out_idx);
 int argmax_blocks(int64_t M);

@@ -722,6 +722,34 @@ void launch_mean_over_draws(hipStream_t s, const double* ei_draw, double* ei_mea
                        ei_draw, ei_mean, M, Mp, H);
 }
 
+// 2-D partition (draws x candidates): this rank's share of sum_h EI[c, h] -- the sum over ITS draws in
+// numpy's order (np.sum(overall_ei[:, h0:h1], axis=1)) -- written into its segment of the zero-padded M-vector that
+// the single all-reduce(SUM) then completes; and the division by the TOTAL number of draws afterwards.
+__global__ __launch_bounds__(256) void k_sum_over_draws(const double* __restrict__ ei_draw,
+                                                        double* __restrict__ out, int64_t M, int64_t Mp, int H)
+{
+#pragma clang fp contract(off)
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= M) return;
+    out[c] = 0.0 + np_pairwise(ei_draw + c, Mp, H);
+}
+
+void launch_sum_over_draws(hipStream_t s, const double* ei_draw, double* out, int64_t M, int64_t Mp, int H)
+{
+    hipLaunchKernelGGL(k_sum_over_draws, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, ei_draw, out, M, Mp, H);
+}
+
+__global__ __launch_bounds__(256) void k_div_scalar(double* __restrict__ v, int64_t n, double denom)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = v[i] / denom;
+}
+
+void launch_div_scalar(hipStream_t s, double* v, int64_t n, double denom)
+{
+    hipLaunchKernelGGL(k_div_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n, denom);
+}
+
 // ---------------------------------------------------------------------------
 // argmax with numpy semantics: the first NaN wins; otherwise the first maximum.
 // ---------------------------------------------------------------------------

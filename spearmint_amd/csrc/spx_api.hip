@@ -137,7 +137,7 @@ void spx_destroy(spx_handle* h)
                           &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
                           &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ybuf,
-                          &h->alphaS, &h->pt_u, &h->rec_send, &h->rec_recv, &h->rec_out};
+                          &h->alphaS, &h->pt_u, &h->rec_send, &h->rec_recv, &h->rec_out, &h->ei_sum_full};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
@@ -621,6 +621,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
         h->st_ms[ST_EI_RUN_TOTAL] += ms; h->st_n[ST_EI_RUN_TOTAL] += 1;
     }
     h->ran = true;
+    h->ran_2d = false;
     h->ran_moments = keep_mom && S == 0;
     if (h->comm) return spx_comm_exchange(h);   // one process per GPU: the winner over all ranks
     return SPX_OK;
@@ -641,7 +642,9 @@ int spx_get_ei_mean(spx_handle* h, double* out)
     if (!h || !out || !h->ran) return fail(SPX_ERR_ARG, "spx_get_ei_mean: no results / null output");
     int rc = ensure_init(h);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(out, h->ei_mean.p, (size_t)h->M * 8, hipMemcpyDeviceToHost));
+    // after the all-reduce of a partitioned run: the GLOBAL mean (all draws of all ranks) of this handle's candidates
+    const double* src = h->ran_2d ? h->ei_sum_full.d() + h->index_base : h->ei_mean.d();
+    HIPCHK(hipMemcpy(out, src, (size_t)h->M * 8, hipMemcpyDeviceToHost));
     return SPX_OK;
 }
 

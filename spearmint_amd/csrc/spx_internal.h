@@ -88,6 +88,12 @@ struct spx_handle {
     bool alphaS_valid = false;
     DevBuf pt_x, pt_k, pt_dk, pt_t, pt_z, pt_out, pt_kt, pt_dkt, pt_u;   // spx_ei_grad_batch work vectors
     DevBuf rec_send, rec_recv, rec_out;   // {best mean EI, global index} records of the multi-GPU all-gather
+    // 2-D partition with a communicator attached (spx_set_partition): the M_total-vector of EI sums / means
+    int part_ph = 1;
+    int64_t part_M = 0;            // > 0: the collective is the all-reduce(SUM) of EI sums
+    int part_H = 0;
+    bool ran_2d = false;
+    DevBuf ei_sum_full;
     DevBuf sobol_dirs, sobol_out;                                   // spx_sobol_grid
     DevBuf rhs;                                                     // spx_gp_logprob: [H][64][Np] right-hand-side rows
     DevBuf diagL;                                                   // spx_gp_logprob (tile-major path): diag(L), [H][Np]

@@ -40,6 +40,7 @@ ABI = {
     "spx_multi_query": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p, _c_int32_p, ctypes.c_int32]),
     "spx_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "spx_comm_attach": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]),
+    "spx_set_partition": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
     "spx_destroy": (None, [_vp]),
     "spx_last_error": (ctypes.c_char_p, []),
     "spx_version": (ctypes.c_int, []),
@@ -182,6 +183,12 @@ class Engine(object):
         if len(uid) != 128:
             raise ValueError("uid must be the 128 bytes of comm_unique_id()")
         self._check(self._lib.spx_comm_attach(self._h, uid, int(nranks), int(rank)))
+
+    def set_partition(self, hyper_shards, M_total=0, H_total=0):
+        """Optional 2-D partition (draws x candidates, one all-reduce(SUM) of the EI-sum vector) -- include/spx.h.
+        Multi-device handle: hyper_shards only (call before set_hypers / set_candidates).  With a communicator
+        attached: this rank's shards are set by the caller, M_total / H_total are the totals."""
+        self._check(self._lib.spx_set_partition(self._h, int(hyper_shards), int(M_total), int(H_total)))
 
     def transport(self):
         """"none" (one GPU), "rccl" (ncclAllGather over the devices) or "host" (repeated device

@@ -446,3 +446,147 @@ def test_plain_c_client_of_the_abi(eng, tmp_path):
     assert best_idx == idx and best_val == val and np.array_equal(mean, m) and np.array_equal(draws, d)
     assert np.array_equal(lp, eng.gp_logprob())
     assert out.decode().startswith("best %d " % idx)
+
+
+# ---- 2-D partition inside the library (spx_set_partition; SURVEY.md 8(e) "hypers x candidates") -----------------------
+def _emulate_2d(eng, comp, vals, cand, hypers, n, ph, per_sec=None):
+    """What dist.shard_2d + dist.allreduce_ei_sums compute for n ranks: every (candidate shard, draw shard) block on a
+    plain one-GPU engine, np.sum over the block's draws, the zero-padded M-vectors added in rank order."""
+    from spearmint_amd import dist as sd
+    M, H = cand.shape[0], hypers.shape[0]
+    full = np.zeros(M)
+    blocks = np.zeros((M, H))
+    for r in range(n):
+        (c0, c1), (h0, h1) = sd.shard_2d(M, H, n, r, ph)
+        if per_sec is None:
+            ei = eng.ei_grid(comp, vals, cand[c0:c1], hypers[h0:h1], want_draws=True)[3]
+        else:
+            ei = eng.ei_per_sec_grid(comp, vals, per_sec[0], cand[c0:c1], hypers[h0:h1], per_sec[1][h0:h1], want_draws=True)[3]
+        blocks[c0:c1, h0:h1] = ei
+        part = np.zeros(M)
+        part[c0:c1] = np.sum(ei, axis=1)
+        full = part if r == 0 else full + part
+    mean = full / float(H)
+    return int(np.argmax(mean)), mean, blocks
+
+
+@pytest.mark.parametrize("devs,ph", [([0, 0], 2), ([0, 0, 0, 0], 2), ([0, 0], 1), ([0, 0, 0, 0, 0, 0], 3)])
+def test_2d_partition_in_the_multi_handle(eng, devs, ph):
+    """draws x candidates over repeated device ids (host transport): the library shards both, keeps the per-device EI
+    sums on the device, reduces them with ONE all-reduce(SUM) and takes the argmax there -- equal, bit for bit, to the
+    host-side scheme of dist.allreduce_ei_sums (two contributions per candidate: the sum is exact in any order)."""
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(150, 2111, 5, 7, 97, per_sec=True)
+    me = MultiEngine(devs)
+    try:
+        me.set_partition(ph)
+        me.set_observations(comp, vals); me.set_hypers(hypers); me.set_candidates(cand)
+        me.factor(); me.ei_run()
+        idx, mean, blocks = _emulate_2d(eng, comp, vals, cand, hypers, len(devs), ph)
+        if ph > 1:
+            assert me.best() == (idx, mean[idx])
+            assert np.array_equal(me.ei_mean(), mean)
+        assert np.array_equal(me.ei_draws(), blocks)          # every (candidate, draw) evaluated once, same bits as 1 GPU
+        one = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        assert np.array_equal(blocks, one[3]) and me.best()[0] == one[0]
+        assert np.allclose(me.ei_mean(), one[2], rtol=1e-14, atol=0)
+        if ph > 1:
+            # per second: the time model's hyper rows are sharded with the draws
+            me.set_time_model(log_durs, th)
+            me.factor(); me.ei_run(1)
+            idx2, mean2, _ = _emulate_2d(eng, comp, vals, cand, hypers, len(devs), ph, per_sec=(log_durs, th))
+            assert me.best() == (idx2, mean2[idx2]) and np.array_equal(me.ei_mean(), mean2)
+            me.set_time_model(None, None)
+            me.factor()
+            # the building blocks follow the partition: a draw's factor lives on the device that owns the draw
+            eng.set_observations(comp, vals); eng.set_hypers(hypers); eng.set_candidates(cand); eng.factor()
+            for d in (0, hypers.shape[0] - 1):
+                assert np.array_equal(me.get_factor(d)[1], eng.get_factor(d)[1])
+                assert np.array_equal(me.get_cross_cov(d, 700, 900), eng.get_cross_cov(d, 700, 900))
+            # a sharded log-likelihood in between must give the devices their draw shards back
+            lp = me.gp_logprob()
+            assert np.array_equal(lp, eng.gp_logprob())
+            me.factor(); me.ei_run()
+            assert me.best() == (idx, mean[idx])
+            with pytest.raises(ValueError):
+                me.ei_grad_batch(np.full((1, 5), 0.5))
+            # not-PD: the failing draw is reported in global numbering
+            bad = hypers.copy(); bad[5, 2] = -1.0
+            me.set_hypers(bad)
+            with pytest.raises(np.linalg.LinAlgError):
+                me.factor()
+            assert me.not_pd_info()[0] == 5
+            # back to candidates only: the plain multi-handle behaviour
+            me.set_partition(1)
+            me.set_hypers(hypers); me.set_candidates(cand); me.factor(); me.ei_run()
+            assert me.best() == (one[0], one[1]) and np.array_equal(me.ei_mean(), one[2])
+        with pytest.raises(ValueError):
+            me.set_partition(len(devs) + 1)
+    finally:
+        me.close()
+
+
+@pytest.mark.timeout(300)
+def test_allreduce_collective_on_an_attached_communicator(eng):
+    """spx_set_partition on a handle with an RCCL communicator (one rank here): spx_ei_run ends with ncclAllReduce(SUM)
+    of the M_total-vector instead of the all-gather of records; with one rank the result is the plain run's."""
+    comp, cand, vals, hypers = synthetic_problem(150, 2500, 5, 4, 91)
+    ref = eng.ei_grid(comp, vals, cand, hypers)
+    e = Engine(0)
+    try:
+        e.comm_attach(e.comm_unique_id(), 1, 0)
+        e.set_partition(1, cand.shape[0], hypers.shape[0])
+        e.set_observations(comp, vals); e.set_hypers(hypers); e.factor()
+        e.set_candidates(cand)
+        e.ei_run()
+        assert e.best() == (ref[0], ref[1]) and np.array_equal(e.ei_mean(), ref[2])
+        # a shard with an offset inside a larger grid: zeros elsewhere, the index is global
+        e.set_candidates(cand[1000:1800], index_base=1000)
+        e.ei_run()
+        sub = eng.ei_grid(comp, vals, cand[1000:1800], hypers)
+        assert e.best() == (sub[0] + 1000, sub[1]) and np.array_equal(e.ei_mean(), sub[2])
+        e.set_candidates(cand[2000:], index_base=2100)           # does not fit M_total
+        with pytest.raises(ValueError):
+            e.ei_run()
+        e.set_partition(1, 0, 0)                                 # back to the all-gather of records
+        e.set_candidates(cand)
+        e.ei_run()
+        assert e.best() == (ref[0], ref[1])
+    finally:
+        e.close()
+
+
+def test_multi_handle_state_after_a_sharded_loglikelihood_and_options(eng):
+    """(1) spx_not_pd_info after a sharded log-likelihood scans only the devices that took part -- an idle
+    device's older non-PD result must not surface; (2) changing covar invalidates the multi handle's results;
+    (3) spx_get_timings is the per-stage maximum over the devices."""
+    comp, cand, vals, hypers = synthetic_problem(200, 600, 4, 7, 63)
+    me = MultiEngine([0, 0, 0])
+    try:
+        me.set_observations(comp, vals)
+        bad = hypers.copy(); bad[4, 2] = -1.0                    # 7 draws over 3 devices: draw 4 lands on device 1
+        me.set_hypers(bad)
+        assert me.gp_logprob()[4] == -np.inf and me.not_pd_info()[0] == 4
+        me.set_hypers(hypers[:1])                                # one row: only device 0 takes part
+        lp = me.gp_logprob(raise_not_pd=True)                    # used to raise a spurious LinAlgError (draw 1 + 0 ...)
+        assert np.isfinite(lp[0]) and me.not_pd_info()[0] == -1
+        me.set_hypers(hypers); me.set_candidates(cand); me.factor()
+        me.set_option("timing", 1)
+        me.ei_run()
+        tm = me.timings()
+        assert tm["predict_gemm"][0] > 0 and tm["ei_run_total"][0] >= tm["predict_gemm"][0]
+        me.set_option("timing", 0)
+        assert me.best()[0] >= 0
+        me.set_covar("Matern32")
+        with pytest.raises(ValueError):
+            me.best()                                            # the factorisation and the winner are stale
+        me.set_covar("Matern52")
+        # a failed set_candidates leaves no half-updated shard table behind
+        with pytest.raises(ValueError):
+            me.set_candidates(np.zeros((10, 3)))                 # wrong D
+        with pytest.raises(ValueError):
+            me.ei_run()
+        me.set_candidates(cand); me.factor(); me.ei_run()
+        one = eng.ei_grid(comp, vals, cand, hypers)
+        assert me.best() == (one[0], one[1])
+    finally:
+        me.close()
