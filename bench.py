@@ -25,7 +25,16 @@ over the WORLD_SIZE ranks ("strong" scaling: total work fixed):
   c5  GPEIperSec dual GP, N_obs=1024, 16-D, 500 000 candidates, mcmc_iters=20
 so `c4.value` at --gpus 1, 2, 4, 8 is the north-star scaling curve.  The
 candidate grid of these is generated in fixed seeded blocks, so every N scores
-the same grid and must report the same best_index.
+the same grid and must report the same best_index.  With N > 1 each of them is
+timed (>= 5 steps) with BOTH forms of the collective -- the 16-byte records
+through torch.distributed (`c4`, `c5`) and through libspx's own ncclAllGather
+on the handle's stream (`c4_lib`, `c5_lib`; spx_comm_attach) -- and, with
+--hyper-shards P_h, C4 also in the 2-D partition (`c4_2d`: host sums + torch
+all-reduce; `c4_2d_lib`: spx_set_partition, ncclAllReduce of the device-resident
+EI-sum vector).  Every record carries the per-rank step times (max / min); a
+variant that cannot run records its error string instead of ending the run, and
+all that ran must agree on the winner.  `--in-process` runs the same headline
+and strong-scaling lines through ONE multi-device handle (spx_create_multi).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel
 (k_predict_gemm_tri: beta = L^-1 K* as an fp64 MFMA GEMM over the lower triangle of
@@ -193,7 +202,7 @@ def main_in_process(args):
     if args.warmup:
         run(args.warmup)
     dt, best = run(args.steps)
-    print(json.dumps({
+    out = {
         "metric": "EI candidate evaluations per second (N_cand x mcmc_iters / wall time)",
         "value": n * float(M) * H * args.steps / dt, "unit": "EI evals/s", "n_gpus": n, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -201,7 +210,57 @@ def main_in_process(args):
         "config": {"workload": w["desc"], "N_obs": N, "candidates_per_gpu": M, "D": D, "mcmc_iters": H,
                    "per_sec": w["per_sec"], "mode": "one process, one multi-device handle (spx_create_multi)",
                    "devices": devs, "transport": eng.transport()},
-        "best_index": best[0], "best_ei": best[1]}))
+        "best_index": best[0], "best_ei": best[1]}
+    # strong scaling through the same handle: the full C4 / C5 grids sharded by the library over the n devices
+    # (and, with --hyper-shards, C4 in the library's 2-D partition: one ncclAllReduce of the EI-sum vector)
+    if not args.skip_extras:
+        esteps = max(args.extra_steps, 5 if n > 1 else 2)
+        variants = [("c4", "c4", 1), ("c5", "c5", 1)]
+        if args.hyper_shards > 1:
+            variants.append(("c4_2d", "c4", args.hyper_shards))
+        for key, name, ph in variants:
+            try:
+                cfg = dict(STRONG[name])
+                cfg["M"] = int(getattr(args, "%s_candidates" % name))
+                sprob, scomp, svals, shyp = strong_problem(cfg)
+                rows = strong_rows(cfg, scomp, svals, 0, cfg["M"])
+                eng.set_partition(ph)
+                eng.set_observations(scomp, svals)
+                eng.set_hypers(shyp)
+                eng.set_candidates(rows)
+                if cfg["per_sec"]:
+                    eng.set_time_model(sprob[4], sprob[5])
+                else:
+                    eng.set_time_model(None, None)
+                fl = FLAG_PER_SEC if cfg["per_sec"] else 0
+                eng.set_option("timing", 0)
+
+                def srun(k):
+                    t0 = time.perf_counter()
+                    for _ in range(k):
+                        eng.factor()
+                        eng.ei_run(fl)
+                        o = eng.best()
+                    return time.perf_counter() - t0, o
+                srun(1)
+                sdt, sbest = srun(esteps)
+                eng.set_option("timing", 1)        # one more step with per-launch events: the per-stage MAX over the devices
+                srun(1)
+                tm = eng.timings()
+                eng.set_option("timing", 0)
+                out[key] = {"value": float(cfg["M"]) * cfg["H"] * esteps / sdt, "unit": "EI evals/s", "scaling": "strong",
+                            "n_gpus": n, "steps": esteps, "warmup": 1, "ms_per_step": sdt / esteps * 1e3,
+                            "partition": "%d draw shards x %d candidate shards" % (ph, n // ph),
+                            "collective": "ncclAllReduce(SUM) of %d doubles" % cfg["M"] if ph > 1 else "ncclAllGather of 16-byte records",
+                            "transport": eng.transport(),
+                            "stages_ms_max_over_devices": {k: v[0] for k, v in tm.items() if v[1]},
+                            "config": {"workload": cfg["desc"], "N_obs": cfg["N"], "candidates_total": cfg["M"],
+                                       "D": cfg["D"], "mcmc_iters": cfg["H"], "per_sec": cfg["per_sec"]},
+                            "best_index": sbest[0], "best_ei": sbest[1]}
+            except Exception as e:      # a variant that cannot run here is reported, not fatal
+                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        eng.set_partition(1)
+    print(json.dumps(out))
     eng.close()
 
 
@@ -311,9 +370,21 @@ def main():
         e.comm_attach(bytes(buf.cpu().numpy().tobytes()), world, rank)
 
     attach(eng)
+    rank_times = {}
 
-    def run_steps(e, fl, nsteps):
-        """nsteps timed steps bracketed by barrier + device sync; MAX over ranks."""
+    def all_ranks(x):
+        """[x of rank 0, ..., x of rank P-1] on every rank (plumbing: per-rank step times, success flags)."""
+        if world == 1:
+            return [float(x)]
+        t = torch.zeros(world, dtype=torch.float64, device=tdev if tdev is not None else "cpu")
+        t[rank] = float(x)
+        tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+        return [float(v) for v in t.cpu().numpy()]
+
+    def run_steps(e, fl, nsteps, lib=None, tag=None):
+        """nsteps timed steps bracketed by barrier + device sync; MAX over ranks.  lib: the collective runs inside
+        libspx (a communicator is attached to `e`), else the records travel through torch.distributed."""
+        lib = lib_collective if lib is None else lib
         out = None
         sync()
         t0 = time.perf_counter()
@@ -321,14 +392,21 @@ def main():
             e.factor()
             e.ei_run(fl)
             idx, val = e.best()
-            out = (idx, val) if lib_collective else spx_dist.exchange_best(val, idx, device=tdev)
+            out = (idx, val) if lib else spx_dist.exchange_best(val, idx, device=tdev)
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        mine = time.perf_counter() - t0          # this rank's own time, before the closing barrier
         sync()
-        return max_over_ranks(time.perf_counter() - t0), out
+        dt_all = max_over_ranks(time.perf_counter() - t0)
+        if tag is not None:
+            per = all_ranks(mine)
+            rank_times[tag] = {"max_ms_per_step": max(per) / nsteps * 1e3, "min_ms_per_step": min(per) / nsteps * 1e3}
+        return dt_all, out
 
     # ---- headline: weak scaling, no per-launch events inside the timed region -------------------
     if args.warmup:
         run_steps(eng, flags, args.warmup)
-    dt, best = run_steps(eng, flags, args.steps)
+    dt, best = run_steps(eng, flags, args.steps, tag="headline")
     evals_per_step = float(M) * H
     value = world * evals_per_step * args.steps / dt
 
@@ -393,6 +471,7 @@ def main():
             "ms_per_step_with_events": dt_ev / ev_steps * 1e3,
             "stages_ms_per_step": {k: v[0] / ev_steps for k, v in tm.items() if v[1]},
             "best_index": best[0], "best_ei": best[1],
+            "rank_step_ms": rank_times.get("headline"),
         }
 
     # ---- the metric as SURVEY 8(d) defines it: host buffers in, result out (PCIe included) ------
@@ -412,63 +491,132 @@ def main():
         assert r[0] == best[0], "one-shot entry point and resident path disagree"
 
     # ---- strong scaling at the full C4 / C5 sizes -------------------------------------------------
+    # With N > 1 ranks every configuration is timed with BOTH forms of the collective in the same run -- the
+    # 16-byte records through torch.distributed (backend nccl = RCCL; sub-records "c4" / "c5") and through libspx's
+    # own ncclAllGather on the handle's stream (spx_comm_attach; "c4_lib" / "c5_lib") -- and, with --hyper-shards,
+    # C4 in the 2-D partition both ways ("c4_2d": host-side sums + torch all-reduce; "c4_2d_lib": spx_set_partition,
+    # ncclAllReduce of the device-resident EI-sum vector).  A variant that cannot run on this box (e.g. two ranks
+    # sharing one GPU cannot form an RCCL communicator) records its error string; the others still count, and all
+    # that ran must agree on the winner.
+    def all_ok(ok):
+        return min(all_ranks(1.0 if ok else 0.0)) > 0.5
+
+    def attach_lib(e):
+        """Attach an RCCL communicator over all ranks to `e`; returns an error string (same decision on every rank)."""
+        err = None
+        try:
+            if world == 1:
+                e.comm_attach(e.comm_unique_id(), 1, 0)
+            else:
+                buf = torch.zeros(128, dtype=torch.uint8, device=tdev if tdev is not None else "cpu")
+                if rank == 0:
+                    buf.copy_(torch.frombuffer(bytearray(e.comm_unique_id()), dtype=torch.uint8))
+                tdist.broadcast(buf, src=0)
+                e.comm_attach(bytes(buf.cpu().numpy().tobytes()), world, rank)
+        except Exception as ex:
+            err = "%s: %s" % (type(ex).__name__, ex)
+        if not all_ok(err is None):
+            return err or "another rank could not attach the communicator"
+        return None
+
     if not args.skip_extras:
+        esteps = max(args.extra_steps, 5) if world > 1 else args.extra_steps
+        winners = {}
         for name in ("c4", "c5"):
             cfg = dict(STRONG[name])
             cfg["M"] = int(getattr(args, "%s_candidates" % name))
             sprob, scomp, svals, shyp = strong_problem(cfg)
             lo, hi = spx_dist.shard_bounds(cfg["M"], world, rank)
             rows = strong_rows(cfg, scomp, svals, lo, hi)
-            e2 = Engine(local_rank)
-            e2.set_observations(scomp, svals)
-            e2.set_candidates(rows, index_base=lo)
-            e2.set_hypers(shyp)
-            if cfg["per_sec"]:
-                e2.set_time_model(sprob[4], sprob[5])
-            attach(e2)
             fl = FLAG_PER_SEC if cfg["per_sec"] else 0
-            run_steps(e2, fl, 1)
-            sdt, sbest = run_steps(e2, fl, args.extra_steps)
-            e2.close()
-            if rank == 0:
-                sval = float(cfg["M"]) * cfg["H"] * args.extra_steps / sdt
-                out[name] = {"value": sval, "unit": "EI evals/s", "scaling": "strong", "n_gpus": world,
-                             "steps": args.extra_steps, "warmup": 1, "ms_per_step": sdt / args.extra_steps * 1e3,
-                             "config": {"workload": cfg["desc"], "N_obs": cfg["N"], "candidates_total": cfg["M"],
-                                        "D": cfg["D"], "mcmc_iters": cfg["H"], "per_sec": cfg["per_sec"]},
-                             "best_index": sbest[0], "best_ei": sbest[1]}
-                out["%s_value" % name] = sval
+            variants = [(name, lib_collective)] if world == 1 else [(name, False), (name + "_lib", True)]
+            for key, use_lib in variants:
+                e2 = None
+                err = None
+                try:
+                    e2 = Engine(local_rank)
+                    e2.set_observations(scomp, svals)
+                    e2.set_candidates(rows, index_base=lo)
+                    e2.set_hypers(shyp)
+                    if cfg["per_sec"]:
+                        e2.set_time_model(sprob[4], sprob[5])
+                except Exception as ex:
+                    err = "%s: %s" % (type(ex).__name__, ex)
+                if not all_ok(err is None):
+                    err = err or "another rank failed to set the problem up"
+                elif use_lib:
+                    err = attach_lib(e2)
+                if err is None:
+                    run_steps(e2, fl, 1, lib=use_lib)
+                    sdt, sbest = run_steps(e2, fl, esteps, lib=use_lib, tag=key)
+                if e2 is not None:
+                    e2.close()
+                if rank == 0:
+                    if err is not None:
+                        out[key] = {"error": err, "n_gpus": world,
+                                    "collective": "libspx ncclAllGather (spx_comm_attach)" if use_lib else "torch.distributed"}
+                        continue
+                    sval = float(cfg["M"]) * cfg["H"] * esteps / sdt
+                    out[key] = {"value": sval, "unit": "EI evals/s", "scaling": "strong", "n_gpus": world,
+                                "steps": esteps, "warmup": 1, "ms_per_step": sdt / esteps * 1e3,
+                                "collective": "libspx ncclAllGather (spx_comm_attach)" if use_lib
+                                              else "torch.distributed all_gather_into_tensor",
+                                "rank_step_ms": rank_times.get(key),
+                                "config": {"workload": cfg["desc"], "N_obs": cfg["N"], "candidates_total": cfg["M"],
+                                           "D": cfg["D"], "mcmc_iters": cfg["H"], "per_sec": cfg["per_sec"]},
+                                "best_index": sbest[0], "best_ei": sbest[1]}
+                    if key == name:
+                        out["%s_value" % name] = sval
+                    winners.setdefault(name, []).append((key, sbest[0], sbest[1]))
+        if rank == 0:
+            for name, ws in winners.items():
+                assert all(w[1:] == ws[0][1:] for w in ws), "collective variants disagree on the winner: %r" % (ws,)
 
     # ---- optional: C4 in the 2-D (draws x candidates) partition, one all-reduce(SUM) of the EI-sum vector ----------
     if args.hyper_shards > 1 and world > 1 and not args.skip_extras:
+        esteps = max(args.extra_steps, 5)
         cfg = dict(STRONG["c4"])
         cfg["M"] = int(args.c4_candidates)
         sprob, scomp, svals, shyp = strong_problem(cfg)
         (lo, hi), (h0, h1) = spx_dist.shard_2d(cfg["M"], cfg["H"], world, rank, args.hyper_shards)
         rows = strong_rows(cfg, scomp, svals, lo, hi)
-        e3 = Engine(local_rank)
-        e3.set_observations(scomp, svals)
-        e3.set_candidates(rows, index_base=lo)
-        e3.set_hypers(shyp[h0:h1])
+        part = "%d draw shards x %d candidate shards" % spx_dist.grid_2d(world, args.hyper_shards)
+        for key, use_lib in (("c4_2d", False), ("c4_2d_lib", True)):
+            e3 = Engine(local_rank)
+            e3.set_observations(scomp, svals)
+            e3.set_candidates(rows, index_base=lo)
+            e3.set_hypers(shyp[h0:h1])
+            err = None
+            if use_lib:
+                err = attach_lib(e3)
+                if err is None:
+                    e3.set_partition(args.hyper_shards, cfg["M"], cfg["H"])
 
-        def step_2d():
-            e3.factor()
-            e3.ei_run(0)
-            sums = np.sum(e3.ei_draws(), axis=1)          # this rank's draws, its candidates
-            return spx_dist.allreduce_ei_sums(sums, lo, cfg["M"], cfg["H"], device=tdev)
-        step_2d()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.extra_steps):
-            r2 = step_2d()
-        sync()
-        dt2 = max_over_ranks(time.perf_counter() - t0)
-        e3.close()
-        if rank == 0:
-            out["c4_2d"] = {"value": float(cfg["M"]) * cfg["H"] * args.extra_steps / dt2, "unit": "EI evals/s",
-                            "scaling": "strong", "n_gpus": world, "partition": "%d draw shards x %d candidate shards"
-                            % spx_dist.grid_2d(world, args.hyper_shards), "collective": "all-reduce(SUM) of %d doubles" % cfg["M"],
-                            "ms_per_step": dt2 / args.extra_steps * 1e3, "best_index": r2[0], "best_ei": r2[1]}
+            def step_2d():
+                e3.factor()
+                e3.ei_run(0)
+                if use_lib:                                       # ncclAllReduce + argmax ran inside spx_ei_run
+                    return e3.best()
+                sums = np.sum(e3.ei_draws(), axis=1)              # this rank's draws, its candidates: D2H of M_local x H_local
+                return spx_dist.allreduce_ei_sums(sums, lo, cfg["M"], cfg["H"], device=tdev)[:2]
+            if err is None:
+                step_2d()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(esteps):
+                    r2 = step_2d()
+                sync()
+                dt2 = max_over_ranks(time.perf_counter() - t0)
+            e3.close()
+            if rank == 0:
+                if err is not None:
+                    out[key] = {"error": err, "n_gpus": world, "partition": part}
+                    continue
+                out[key] = {"value": float(cfg["M"]) * cfg["H"] * esteps / dt2, "unit": "EI evals/s",
+                            "scaling": "strong", "n_gpus": world, "partition": part, "steps": esteps,
+                            "collective": ("libspx ncclAllReduce(SUM) of %d doubles on the handle's stream (spx_set_partition)"
+                                           if use_lib else "host-side sums + torch all-reduce(SUM) of %d doubles") % cfg["M"],
+                            "ms_per_step": dt2 / esteps * 1e3, "best_index": int(r2[0]), "best_ei": float(r2[1])}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -164,6 +164,20 @@ def test_bench_two_ranks_equals_one_rank_over_concatenated_candidates(eng):
     # mean EI equal up to the order of the sum over draws
     assert out["c4_2d"]["best_index"] == out["c4"]["best_index"]
     assert abs(out["c4_2d"]["best_ei"] - out["c4"]["best_ei"]) <= 1e-13 * abs(out["c4"]["best_ei"])
+    # N > 1: at least 5 timed steps per sub-record, per-rank step times (a straggler shows) ...
+    assert out["c4"]["steps"] >= 5 and out["c5"]["steps"] >= 5
+    for key in ("c4", "c5"):
+        rt = out[key]["rank_step_ms"]
+        assert 0 < rt["min_ms_per_step"] <= rt["max_ms_per_step"] <= out[key]["ms_per_step"] * 1.05
+    assert out["rank_step_ms"]["max_ms_per_step"] > 0
+    # ... and every variant of the collective was attempted in this one run.  Two ranks on ONE device cannot form an
+    # RCCL communicator: the library-collective variants must report that as an error string (not die, not hang),
+    # leaving the other records intact -- on distinct GPUs they carry numbers and must agree on the winner.
+    for key in ("c4_lib", "c5_lib", "c4_2d_lib"):
+        rec = out[key]
+        assert ("error" in rec and rec["error"]) or rec["best_index"] == out[key.split("_")[0]]["best_index"], rec
+    assert "error" in out["c4_lib"] and ("nccl" in out["c4_lib"]["error"].lower() or "rccl" in out["c4_lib"]["error"].lower()
+                                         or "communicator" in out["c4_lib"]["error"].lower())
 
 
 # ---- spx_ei_grad_batch: the refinement objective ---------------------------------------------------
@@ -288,7 +302,7 @@ def test_bench_in_process_mode_matches_the_default_mode(eng):
     """bench.py --in-process: the weak-scaling headline through one multi-device handle (the RCCL path of
     libspx; here a communicator of one device) must pick the same candidate as the default mode."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--in-process", "--gpus", "1", "--steps", "1", "--warmup", "0",
-           "--workload", "c2"]
+           "--workload", "c2", "--c4-candidates", "30000", "--c5-candidates", "20000", "--hyper-shards", "2"]
     res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
@@ -305,6 +319,20 @@ def test_bench_in_process_mode_matches_the_default_mode(eng):
     s1 = bench.weak_problem(w, 1)[4]
     idx, val, _, _ = eng.ei_grid(comp, vals, np.vstack((s0, s1)), hypers)
     assert out["config"]["transport"] == "host" and (out["best_index"], out["best_ei"]) == (idx, val)
+    # the strong-scaling lines of this mode: the full grids sharded by the library over the handle's devices, and C4
+    # in the library's 2-D partition (2 draw shards x 1 candidate shard)
+    for name, M in (("c4", 30000), ("c5", 20000)):
+        cfg = dict(bench.STRONG[name]); cfg["M"] = M
+        prob, scomp, svals, shyp = bench.strong_problem(cfg)
+        rows = bench.strong_rows(cfg, scomp, svals, 0, M)
+        if cfg["per_sec"]:
+            i1, v1, _, _ = eng.ei_per_sec_grid(scomp, svals, prob[4], rows, shyp, prob[5])
+        else:
+            i1, v1, _, _ = eng.ei_grid(scomp, svals, rows, shyp)
+        assert (out[name]["best_index"], out[name]["best_ei"]) == (i1, v1) and out[name]["scaling"] == "strong"
+        assert out[name]["stages_ms_max_over_devices"]["predict_gemm"] > 0
+    assert out["c4_2d"]["best_index"] == out["c4"]["best_index"] and "ncclAllReduce" in out["c4_2d"]["collective"]
+    assert abs(out["c4_2d"]["best_ei"] - out["c4"]["best_ei"]) <= 1e-13 * abs(out["c4"]["best_ei"])
 
 
 @pytest.mark.timeout(300)
