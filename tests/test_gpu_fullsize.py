@@ -127,7 +127,7 @@ def test_c4_full_million_candidates_and_eight_shards(eng):
     assert sd.pick_best(recs) == (idx, val)
     topk = 1000
     top = np.argsort(mean)[::-1][:topk]
-    rnd = np.random.RandomState(1).choice(M, 4000, replace=False)
+    rnd = np.random.RandomState(1).choice(M, 20000, replace=False)      # an oracle subsample >= 20k
     sub = np.concatenate((top, np.setdiff1d(rnd, top)))
     ref = orc.ei_grid_chunked(comp, cand[sub], vals, hypers)
     check_winner(mean, idx, draws[sub], ref, sub, topk)
@@ -150,7 +150,7 @@ def test_c5_full_half_million_candidates_per_second(eng):
     assert sd.pick_best(recs) == (idx, val)
     topk = 1000
     top = np.argsort(mean)[::-1][:topk]
-    rnd = np.random.RandomState(2).choice(M, 4000, replace=False)
+    rnd = np.random.RandomState(2).choice(M, 20000, replace=False)      # an oracle subsample >= 20k
     sub = np.concatenate((top, np.setdiff1d(rnd, top)))
     ref = orc.ei_per_s_over_hypers(comp, cand[sub], vals, log_durs, hypers, th)
     check_winner(mean, idx, draws[sub], ref, sub, topk)
