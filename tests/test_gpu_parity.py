@@ -533,3 +533,43 @@ def test_whole_branin_runs_on_gpu_match_reference(golden_dir, tmp_path, extra):
     device log-likelihood and the batched device refinement forced on."""
     from tests.test_host_logic import _trajectory_runs
     _trajectory_runs(golden_dir, tmp_path, lambda: None, extra)
+
+
+@pytest.mark.parametrize("npend,multi", [(0, False), (3, False), (0, True), (2, True)])
+def test_opt_chooser_rescore_grid_does_not_change_the_proposal(tmp_path, npend, multi):
+    """with rescore_grid=0 (default) the second EI pass of GPEIOptChooser keeps the pass-1 values of
+    the grid rows and scores only the refined points; rescore_grid=1 runs the reference's literal second pass over
+    [grid; refined].  They agree only while a candidate's EI is bit-independent of which other candidates (and which
+    chunk / tile / device shard) share the call -- asserted here: same proposal and the same mean-EI vector, without
+    and with pending jobs (fantasies), on one engine and on a multi-device handle (three engines on the one GPU)."""
+    from spearmint_amd.chooser import GPEIOptChooser
+    from spearmint_amd.engine import MultiEngine
+    comp, cand, vals, _ = synthetic_problem(150, 2600, 4, 1, 77)
+    rs = np.random.RandomState(5)
+    pend = rs.rand(npend, 4)
+    grid = np.vstack((comp, cand, pend))
+    n, m = comp.shape[0], cand.shape[0]
+    values = np.concatenate((vals, np.full(m + npend, np.nan)))
+    durations = np.ones(grid.shape[0])
+    complete, candidates, pending = np.arange(n), np.arange(n, n + m), np.arange(n + m, n + m + npend)
+    out = []
+    for rescore in (0, 1):
+        d = tmp_path / ("r%d" % rescore)
+        d.mkdir()
+        ch = GPEIOptChooser.init(str(d), "mcmc_iters=3,burnin=1,grid_subset=4,use_multiprocessing=0,gpu_refine=1,"
+                                         "gpu_logprob=1,rescore_grid=%d" % rescore)
+        if multi:
+            ch._eng = MultiEngine([0, 0, 0])
+            ch._eng.set_covar(ch.covar)
+            ch._eng.set_option("kstar_budget_bytes", 160 * 1024 * 8)      # several chunks per shard as well
+        npr.seed(19)
+        job = ch.next(grid, values, durations, candidates, pending, complete)
+        out.append((job, np.array(ch.last_ei_mean)))
+        ch.engine().close()
+    (j0, m0), (j1, m1) = out
+    # rescore_grid=1 leaves the means of [grid; refined]; rescore_grid=0 those of the refined points only
+    assert np.array_equal(m0, m1[m:])
+    if isinstance(j0, tuple):
+        assert isinstance(j1, tuple) and j0[0] == j1[0] and np.array_equal(j0[1], j1[1])
+    else:
+        assert j0 == j1

@@ -301,6 +301,8 @@ def test_lbfgs_many_equals_serial_scipy():
         assert np.array_equal(got[i], ref)
     assert batches[0] == 7 and min(batches) >= 1 and len(batches) < sum(batches)   # really batched
     assert refine.lbfgs_many(f_many, np.zeros((0, 5)), bounds).shape == (0, 5)
+    # the serial fallback (serial=True / SPX_REFINE_SERIAL=1, for a scipy whose fmin_l_bfgs_b is not re-entrant)
+    assert np.array_equal(refine.lbfgs_many(f_many, pts, bounds, serial=True), got)
 
 
 def test_lbfgs_many_propagates_errors():
@@ -310,6 +312,24 @@ def test_lbfgs_many_propagates_errors():
         raise RuntimeError("objective failed")
     with pytest.raises(RuntimeError):
         refine.lbfgs_many(boom, np.random.rand(3, 2), [(0, 1)] * 2)
+
+
+def test_lbfgs_many_abort_releases_its_threads():
+    """Leaving the dispatch loop abnormally (here: KeyboardInterrupt out of the objective callback) must not strand
+    the L-BFGS-B instances on the condition variable: they are aborted and joined, the interrupt propagates."""
+    import threading
+    from spearmint_amd import refine
+    before = threading.active_count()
+    calls = []
+
+    def interrupt(X):
+        calls.append(len(X))
+        if len(calls) == 2:
+            raise KeyboardInterrupt()
+        return np.sum(X ** 2, axis=1), 2 * X
+    with pytest.raises(KeyboardInterrupt):
+        refine.lbfgs_many(interrupt, np.random.RandomState(1).rand(4, 3) + 0.2, [(0, 2)] * 3)
+    assert threading.active_count() == before
 
 
 def test_opt_next_with_batched_refinement_matches_reference(golden_dir, tmp_path):
