@@ -1,0 +1,25 @@
+"""Dev tool: spx_gp_logprob -- the pair path (option lean_pair=1) against the default: bits and wall time per call."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from spearmint_amd.engine import Engine
+from spearmint_amd.synthetic import synthetic_problem
+eng = Engine(0)
+for N, D in ((2048, 32), (1000, 16), (512, 16), (256, 8), (100, 4)):
+    for H in (1, 2, 4, 6, 8, 12, 20, 32):
+        comp, cand, vals, hypers = synthetic_problem(N, 16, D, H, 5)
+        if H >= 4:
+            hypers[2, 2] = -1.0      # a non-PD draw in the batch
+        eng.set_observations(comp, vals)
+        res, tms = [], []
+        for pair in (0, 1):
+            eng.set_option("lean_pair", pair)
+            eng.set_hypers(hypers); res.append(eng.gp_logprob())
+            t = time.time()
+            for _ in range(20):
+                eng.set_hypers(hypers); eng.gp_logprob()
+            tms.append((time.time() - t) / 20 * 1e3)
+        same = np.array_equal(res[0], res[1])
+        print("N=%4d H=%2d  default %.3f ms  pair %.3f ms  (%+.1f %%)  bit-identical %s%s"
+              % (N, H, tms[0], tms[1], (tms[1] / tms[0] - 1) * 100, same, "" if same else "   <-- FAIL  max diff %.3e" % np.nanmax(np.abs(res[0] - res[1]))))
+eng.set_option("lean_pair", -1)

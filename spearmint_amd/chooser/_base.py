@@ -79,6 +79,7 @@ class GPEIBase(object):
             _sobol.install(device=self.device, log=log)
         self._lp_key = None
         self._lp_refs = None
+        self._slice_hist = {}     # per kind of move: how the ends of the slice bracket behaved (util._slice_along_batched)
         self.D = -1
         self._eng = None          # created lazily in next(): never before a fork, never pickled
         self.last_overall_ei = None
@@ -183,7 +184,7 @@ class GPEIBase(object):
         lp = eng.gp_logprob()
         return lp, np.isneginf(lp)
 
-    def _speculative_logprob(self, comp, vals, to_row, finish):
+    def _speculative_logprob(self, comp, vals, to_row, finish, kind="ls"):
         """Adapter for util.slice_sample_batched: `to_row(x)` gives the hyper row to evaluate or
         None when x is rejected a priori (-inf without touching the GP, as the reference's
         closures do); `finish(x, data_lp)` adds the priors."""
@@ -221,6 +222,10 @@ class GPEIBase(object):
                 memo.clear()
                 memo.update(fresh)
             return util._LazyValues(values, errors)
+        # what lets the sampler plan its speculative batches: where the log-probability is -inf whatever the data
+        # say, and how the two ends of the bracket behaved in this chooser's earlier moves of the same kind
+        many.admissible = lambda x: to_row(x) is not None
+        many.history = self.__dict__.setdefault("_slice_hist", {}).setdefault(kind, {"lo": [1.0, 1.0, 0.0], "hi": [1.0, 1.0, 0.0]})
         return many
 
     # -- hyper-parameter sampling (host; GPEIChooser.py:268-346) -----------------
@@ -265,7 +270,7 @@ class GPEIBase(object):
             def to_row(h):
                 ok = admissible(h)
                 return None if ok is None else np.concatenate(([ok[0], ok[2], ok[1]], ls))
-            new = util.slice_sample_batched(start, self._speculative_logprob(comp, vals, to_row, priors),
+            new = util.slice_sample_batched(start, self._speculative_logprob(comp, vals, to_row, priors, kind="joint"),
                                             compwise=False, lookahead=self.lookahead)
         else:
             new = util.slice_sample(start, logprob, compwise=False)

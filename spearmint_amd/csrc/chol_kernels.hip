@@ -144,7 +144,8 @@ __device__ __forceinline__ void factor16_mfma(d4& C, d4& Xo, d4& U, int lane, in
 }
 
 // ---------------------------------------------------------------------------
-// Factor the 64x64 block held (full, symmetric) in S and invert the factor; 256 threads.
+// Factor the 64x64 block held (full, symmetric) in S and invert the factor; 256 threads (a larger workgroup may
+// call it too: waves 4 and up only take part in the barriers).
 //   S   [64][LDP]  in: the updated diagonal block; out: L_kk in the lower triangle
 //   XT  [64][LDP]  out: (L_kk^-1)^T
 //   T16 [4][16][18] scratch: inverses of the 16x16 diagonal sub-blocks
@@ -222,7 +223,7 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
     int bad = 0;
     d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};     // waves 1-3: inner sum of the last row of the inverse (column wave - 1)
     STAMP(0);
-    if (wave > 0) {
+    if (wave > 0 && wave < 4) {
         // The inverse goes to global memory block by block from the registers of the wave that computes it; the
         // blocks above the block diagonal are zero: (0,1) (0,2) | (0,3) (1,2) | (1,3) (2,3) for waves 1 | 2 | 3.
         const int zi0 = (wave == 3) ? 1 : 0, zj0 = (wave == 1) ? 1 : 3;
@@ -249,7 +250,7 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                 Tb[row * 18 + li] = X[r];                       // Linv16[row][col = li]
                 XT[(b0 + li) * LDP + b0 + row] = X[r];          // XT[col][row] = X[row][col]
             }
-        } else if (b > 0) {
+        } else if (b > 0 && wave < 4) {
             // trailing tiles of round b-1 other than (b,b): (ti,tj), b-1 < tj <= ti, dealt to waves 1-3
             int idx = 0;
             for (int ti = b; ti < 4; ++ti)
@@ -296,13 +297,13 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         if (*info_h == 0) *info_h = bad;
     }
     // last row of the inverse: one product with Linv16_3 per block (rows 0-2 went out as they were built)
-    if (wave > 0) inv_finish(t4, XT, T16, Dk, 3, wave - 1, g, li);
+    if (wave > 0 && wave < 4) inv_finish(t4, XT, T16, Dk, 3, wave - 1, g, li);
     STAMP(17);
     // L_kk (upper part zero), 16 bytes per lane (S is complete since the last barrier); the log-likelihood path
     // only needs its diagonal (diag_out)
     if (diag_out && threadIdx.x < NB) diag_out[threadIdx.x] = S[threadIdx.x * LDP + threadIdx.x];
     if (Lkk) {
-        for (int idx = threadIdx.x; idx < NB * NB / 2; idx += 256) {
+        for (int idx = threadIdx.x; idx < NB * NB / 2; idx += blockDim.x) {
             const int row = idx >> 5, col = (idx & 31) * 2;
             d2 lv;
             lv[0] = (col <= row) ? S[row * LDP + col] : 0.0;
@@ -805,6 +806,219 @@ void launch_lean_logprob_y(hipStream_t s, const double* diagL, const double* ybu
                            int Np, int nh)
 {
     hipLaunchKernelGGL(k_lean_logprob_y, dim3(nh), dim3(256), 0, s, diagL, ybuf, info, out, N, Np);
+}
+
+// ---------------------------------------------------------------------------
+// k_pair_step / k_pair_trsm: TWO block columns per pair of launches, 1024-thread workgroups.
+//
+// What bounds a log-likelihood call with a handful of draws is the dependent chain of the block columns: per column
+// two launches (update + diagonal block; panel solve), ~28 us of which 14 are the diagonal block's pivots.  Here a
+// pair of columns (k, k + 1), k even, costs two launches:
+//   k_pair_step(k)  every remaining tile takes the steps k-2 and k-1 in one pass (accumulators in registers across
+//                   both, as in k_lean_step2: half the tile traffic) -- and ONE workgroup per draw walks the 2x2
+//                   corner: tile (k,k) -> its diagonal block; tile (k+1,k) -> L_k+1,k = R Dinv_k^T (it needs no
+//                   launch boundary: Dinv_k is this workgroup's own); tile (k+1,k+1), which thereby also takes step
+//                   k -> its diagonal block.
+//   k_pair_trsm(k)  per block row i >= k+2 (and the right-hand-side rows): L_ik = R_ik Dinv_k^T, then tile
+//                   (i,k+1) takes step k and is solved against Dinv_k+1.
+// Every tile still receives its steps in the order 0, 1, 2, ... through the same 64-deep MFMA chains, so the
+// factor keeps its bits.  Workgroups have SIXTEEN wavefronts, wave (wr, wc) owning the 16x16 sub-block (wr, wc)
+// of a tile (one accumulator register quad per tile): a tile product is 16 MFMAs per wave -- 0.43 us of matrix pipe
+// instead of 1.7 -- which is what makes the corner workgroup's eight extra products affordable, and such a
+// workgroup fills its CU (1024 threads), so the wave that runs the pivots shares its SIMD with nobody else's MFMAs.
+#define P16_THREADS 1024
+
+// sub-block (wr, wc) of a tile in tile-major storage: values q = 4 wc + r of thread slot t = 64 wr + lane
+__device__ __forceinline__ d4 load_sub(const double* __restrict__ tile, int wr, int wc, int lane)
+{
+    const d2* p = reinterpret_cast<const d2*>(tile) + (64 * wr + lane);
+    const d2 lo = p[(2 * wc) * 256], hi = p[(2 * wc + 1) * 256];
+    return (d4){lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ void store_sub(double* __restrict__ tile, const d4& v, int wr, int wc, int lane)
+{
+    d2* p = reinterpret_cast<d2*>(tile) + (64 * wr + lane);
+    p[(2 * wc) * 256] = (d2){v[0], v[1]};
+    p[(2 * wc + 1) * 256] = (d2){v[2], v[3]};
+}
+// element (16 wr + g + 4 r, 16 wc + li) of the [64][LDP] operand layout
+__device__ __forceinline__ void sub_to_lds(const d4& v, double* lds, int wr, int wc, int g, int li)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds[(16 * wr + g + 4 * r) * LDP + 16 * wc + li] = v[r];
+}
+// acc (+/-)= A[16 wr + .][:] . B[16 wc + .][:]^T, the 64-deep chain of mma_tile_64
+__device__ __forceinline__ void mma_sub(const double* A, const double* B, d4& acc, int wr, int wc, int g, int li, bool negate)
+{
+#pragma unroll 4
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        double a = A[(16 * wr + li) * LDP + k0 + g];
+        if (negate) a = -a;
+        acc = MFMA_F64(a, B[(16 * wc + li) * LDP + k0 + g], acc);
+    }
+}
+// a row-major [64][64] block (Dinv) -> [64][LDP], 1024 threads
+__device__ __forceinline__ void rowmajor_to_lds16(const double* __restrict__ g, double* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = threadIdx.x + P16_THREADS * q;  // double2 units
+        const int row = idx >> 5, c2 = idx & 31;
+        *reinterpret_cast<d2*>(lds + row * LDP + 2 * c2) = *reinterpret_cast<const d2*>(g + (size_t)row * NB + 2 * c2);
+    }
+}
+
+__global__ __launch_bounds__(P16_THREADS) void k_pair_step(double* __restrict__ Lt, double* __restrict__ Dinv,
+                                                           int* __restrict__ info, double* __restrict__ rhs,
+                                                           double* __restrict__ diagL, int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* U0 = smem;                  // [64][LDP]
+    double* U1 = smem + NB * LDP;       // [64][LDP]
+    double* U2 = smem + 2 * NB * LDP;   // [64][LDP]
+    double* T16 = smem + 3 * NB * LDP;  // [4][16][18]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int h = blockIdx.x;           // draws on x: the corner workgroups of all draws are dispatched first
+    const int nblk = Np / NB;
+    const bool is_rhs = blockIdx.y == gridDim.y - 1;
+    const int i = k + blockIdx.y;
+    double* Lh = Lt + (size_t)h * Np * Np;
+    const int npass = (k >= 2) ? 2 : 0;
+    if (!is_rhs && i <= k + 1) {
+        if (i == k + 1 || blockIdx.z > 0) return;        // the corner's three tiles belong to ONE workgroup
+        // ---- the 2x2 corner ----
+        double* r0 = Lh + (size_t)k * nblk * LEAN_TILE;          // tiles (k, .)
+        double* r1 = Lh + (size_t)(k + 1) * nblk * LEAN_TILE;    // tiles (k+1, .)
+        d4 a00 = load_sub(r0 + (size_t)k * LEAN_TILE, wr, wc, lane);
+        d4 a10 = load_sub(r1 + (size_t)k * LEAN_TILE, wr, wc, lane);
+        d4 a11 = load_sub(r1 + (size_t)(k + 1) * LEAN_TILE, wr, wc, lane);
+        for (int pass = 0; pass < npass; ++pass) {
+            const int p = k - 2 + pass;
+            const d4 t0 = load_sub(r0 + (size_t)p * LEAN_TILE, wr, wc, lane);
+            const d4 t1 = load_sub(r1 + (size_t)p * LEAN_TILE, wr, wc, lane);
+            if (pass) __syncthreads();
+            sub_to_lds(t0, U0, wr, wc, g, li);
+            sub_to_lds(t1, U1, wr, wc, g, li);
+            __syncthreads();
+            mma_sub(U0, U0, a00, wr, wc, g, li, true);
+            mma_sub(U1, U0, a10, wr, wc, g, li, true);
+            mma_sub(U1, U1, a11, wr, wc, g, li, true);
+        }
+        __syncthreads();
+        sub_to_lds(a00, U0, wr, wc, g, li);
+        __syncthreads();
+        double* Dk0 = Dinv + ((size_t)h * nblk + k) * NB * NB;
+        diag_block(U0, U1, T16, info + h, k * NB, nullptr, 0, Dk0, diagL + (size_t)h * Np + (size_t)k * NB);
+        __syncthreads();                                    // Dinv_k is in global memory (this workgroup's own stores)
+        rowmajor_to_lds16(Dk0, U2);
+        sub_to_lds(a10, U0, wr, wc, g, li);                 // R_k+1,k
+        __syncthreads();
+        d4 l10 = (d4){0.0, 0.0, 0.0, 0.0};
+        mma_sub(U0, U2, l10, wr, wc, g, li, false);         // L_k+1,k = R Dinv_k^T
+        store_sub(r1 + (size_t)k * LEAN_TILE, l10, wr, wc, lane);
+        sub_to_lds(l10, U1, wr, wc, g, li);
+        __syncthreads();
+        mma_sub(U1, U1, a11, wr, wc, g, li, true);          // step k of tile (k+1, k+1)
+        __syncthreads();
+        sub_to_lds(a11, U0, wr, wc, g, li);
+        __syncthreads();
+        diag_block(U0, U1, T16, info + h, (k + 1) * NB, nullptr, 0, Dinv + ((size_t)h * nblk + k + 1) * NB * NB,
+                   diagL + (size_t)h * Np + (size_t)(k + 1) * NB);
+        return;
+    }
+    // ---- every other tile: the steps k-2 and k-1 ----
+    if (npass == 0) return;
+    const int j0 = k + blockIdx.z * LEAN_CH;
+    const int j1 = min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
+    if (j0 >= j1) return;
+    const int nc = j1 - j0;
+    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;
+    d4 acc[LEAN_CH];
+#pragma unroll
+    for (int c = 0; c < LEAN_CH; ++c)
+        if (c < nc) acc[c] = load_sub(row + (size_t)(j0 + c) * LEAN_TILE, wr, wc, lane);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p = k - 2 + pass;
+        const d4 ta = load_sub(row + (size_t)p * LEAN_TILE, wr, wc, lane);
+        d4 tb = load_sub(Lh + ((size_t)j0 * nblk + p) * LEAN_TILE, wr, wc, lane);
+        if (pass) __syncthreads();
+        sub_to_lds(ta, U0, wr, wc, g, li);
+#pragma unroll
+        for (int c = 0; c < LEAN_CH; ++c)
+            if (c < nc) {
+                double* B = (c & 1) ? U2 : U1;              // two column-operand buffers: one barrier per tile
+                sub_to_lds(tb, B, wr, wc, g, li);
+                __syncthreads();
+                if (c + 1 < nc) tb = load_sub(Lh + ((size_t)(j0 + c + 1) * nblk + p) * LEAN_TILE, wr, wc, lane);
+                mma_sub(U0, B, acc[c], wr, wc, g, li, true);
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < LEAN_CH; ++c)
+        if (c < nc) store_sub(row + (size_t)(j0 + c) * LEAN_TILE, acc[c], wr, wc, lane);
+}
+
+// the panel of the pair (k, k+1) for block row i >= k+2 / the right-hand-side rows
+__global__ __launch_bounds__(P16_THREADS) void k_pair_trsm(double* __restrict__ Lt, const double* __restrict__ Dinv,
+                                                           double* __restrict__ rhs, int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* U0 = smem;
+    double* U1 = smem + NB * LDP;
+    double* U2 = smem + 2 * NB * LDP;
+    double* U3 = smem + 3 * NB * LDP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int h = blockIdx.y;
+    const int nblk = Np / NB;
+    const bool is_rhs = blockIdx.x == gridDim.x - 1;
+    const int i = k + 2 + blockIdx.x;
+    double* Lh = Lt + (size_t)h * Np * Np;
+    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;
+    const double* Dk0 = Dinv + ((size_t)h * nblk + k) * NB * NB;
+    const d4 r0 = load_sub(row + (size_t)k * LEAN_TILE, wr, wc, lane);
+    d4 a1 = load_sub(row + (size_t)(k + 1) * LEAN_TILE, wr, wc, lane);
+    const d4 l10 = load_sub(Lh + ((size_t)(k + 1) * nblk + k) * LEAN_TILE, wr, wc, lane);
+    rowmajor_to_lds16(Dk0, U1);
+    rowmajor_to_lds16(Dk0 + NB * NB, U3);                     // Dinv_k+1 follows Dinv_k
+    sub_to_lds(r0, U0, wr, wc, g, li);
+    sub_to_lds(l10, U2, wr, wc, g, li);
+    __syncthreads();
+    d4 l0 = (d4){0.0, 0.0, 0.0, 0.0};
+    mma_sub(U0, U1, l0, wr, wc, g, li, false);                // L_ik = R_ik Dinv_k^T
+    store_sub(row + (size_t)k * LEAN_TILE, l0, wr, wc, lane);
+    __syncthreads();
+    sub_to_lds(l0, U0, wr, wc, g, li);
+    __syncthreads();
+    mma_sub(U0, U2, a1, wr, wc, g, li, true);                 // step k of tile (i, k+1)
+    __syncthreads();
+    sub_to_lds(a1, U0, wr, wc, g, li);
+    __syncthreads();
+    d4 l1 = (d4){0.0, 0.0, 0.0, 0.0};
+    mma_sub(U0, U3, l1, wr, wc, g, li, false);                // L_i,k+1 = R Dinv_k+1^T
+    store_sub(row + (size_t)(k + 1) * LEAN_TILE, l1, wr, wc, lane);
+}
+
+void launch_pair_step(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int Np, int k, int nh)
+{
+    const int n = Np / NB - k;       // block rows k .. nblk-1 (n >= 2, even)
+    if (n < 2) return;
+    const size_t lds = (size_t)(3 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 110.6 KB: one workgroup per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // k = 0: nothing to apply yet, only the corner workgroups (row 0; the last row of the grid is the rhs row)
+    const dim3 grid = (k == 0) ? dim3(nh, 2, 1) : dim3(nh, n + 1, (n + LEAN_CH - 1) / LEAN_CH);
+    hipLaunchKernelGGL(k_pair_step, grid, dim3(P16_THREADS), lds, s, Lt, Dinv, info, rhs, diagL, Np, k);
+}
+
+void launch_pair_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs, int Np, int k, int nh)
+{
+    const int nrows = Np / NB - k - 2;   // block rows below the pair; + the right-hand-side rows
+    const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);   // 135 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_pair_trsm, dim3(nrows + 1, nh), dim3(P16_THREADS), lds, s, Lt, Dinv, rhs, Np, k);
 }
 
 // lazy = 1: updates are applied two steps at a time (k_lean_step2 at even k >= 2; at odd k only block column k is

@@ -265,6 +265,61 @@ def test_speculative_sampler_is_the_same_markov_chain(golden_dir):
         sb = npr.get_state()
         assert np.array_equal(np.array(a), np.array(b))
         assert np.array_equal(sa[1], sb[1]) and sa[2] == sb[2]
+    # With the priors' support known a priori (`admissible`) and a record of how the bracket's ends behaved in earlier
+    # moves (`history`), the sampler also speculates on an end stepping out to the edge of the support: still the same
+    # chain and RNG state -- and fewer batches where that is what the moves do (sigma well above the support's width)
+    batches = {}
+
+    def counting(xs):
+        batches[counting.tag] = batches.get(counting.tag, 0) + 1
+        return many(xs)
+    for compwise, sigma, la in [(True, 1.0, 6), (True, 1.0, 2), (True, 0.4, 4), (False, 1.0, 6), (True, 3.0, 6), (True, 3.0, 3)]:
+        npr.seed(12); a = [np.ones(3)]
+        for _ in range(40):
+            a.append(util.slice_sample(a[-1], lp_ls, sigma=sigma, compwise=compwise))
+        sa = npr.get_state()
+        for with_adm in (False, True):
+            counting.tag = (sigma, la, with_adm)
+            for attr in ("admissible", "history"):
+                if hasattr(counting, attr):
+                    delattr(counting, attr)
+            if with_adm:
+                counting.admissible = lambda x: not (np.any(x < 0) or np.any(x > 2))
+                counting.history = {"lo": [1.0, 1.0, 0.0], "hi": [1.0, 1.0, 0.0]}
+            npr.seed(12); b = [np.ones(3)]
+            for _ in range(40):
+                b.append(util.slice_sample_batched(b[-1], counting, sigma=sigma, compwise=compwise, lookahead=la))
+            sb = npr.get_state()
+            assert np.array_equal(np.array(a), np.array(b))
+            assert np.array_equal(sa[1], sb[1]) and sa[2] == sb[2]
+    # a log-probability that pushes against the upper edge of the support (what the length scales of a 32-D problem
+    # do under their top-hat prior): the upper end of the bracket steps out to the edge in most moves, the planner
+    # learns it, and the chain -- unchanged -- needs fewer batches
+    def lp_push(x):
+        return -np.inf if (np.any(x < 0) or np.any(x > 2)) else 4.0 * float(np.sum(x))
+
+    def many_push(xs):
+        many_push.n += 1
+        return util._LazyValues([lp_push(x) for x in xs], [None] * len(xs))
+    npr.seed(5); a = [np.ones(4)]
+    for _ in range(60):
+        a.append(util.slice_sample(a[-1], lp_push, compwise=True))
+    sa = npr.get_state()
+    count = {}
+    for with_adm in (False, True):
+        for attr in ("admissible", "history"):
+            if hasattr(many_push, attr):
+                delattr(many_push, attr)
+        if with_adm:
+            many_push.admissible = lambda x: not (np.any(x < 0) or np.any(x > 2))
+            many_push.history = {"lo": [1.0, 1.0, 0.0], "hi": [1.0, 1.0, 0.0]}
+        many_push.n = 0
+        npr.seed(5); b = [np.ones(4)]
+        for _ in range(60):
+            b.append(util.slice_sample_batched(b[-1], many_push, compwise=True, lookahead=6))
+        assert np.array_equal(np.array(a), np.array(b)) and np.array_equal(sa[1], npr.get_state()[1])
+        count[with_adm] = many_push.n
+    assert count[True] < 0.85 * count[False], count
     # golden trace of the REFERENCE's sampler through the batched code path
     npr.seed(77)
     x = g["compwise"][0]
