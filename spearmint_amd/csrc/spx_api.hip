@@ -174,10 +174,6 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
-    if (!strcmp(name, "lean_pair")) {   // log-likelihood path: two block columns per pair of launches (1), one (0), default (-1)
-        h->lean_pair = value < 0 ? -1 : (value != 0);
-        return SPX_OK;
-    }
     if (!strcmp(name, "lean_fused")) {  // log-likelihood path: one launch per block column (1), step + panel solve (0), by size (-1, default)
         h->lean_fused = value < 0 ? -1 : (value != 0);
         return SPX_OK;
@@ -352,18 +348,11 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     // vs 1.33 ms) -- its MFMA-heavy workgroups share SIMDs with the wave that runs the pivots -- so by default it is
     // chosen by size (option lean_fused = -1); 0 / 1 force either form.
     const int want_fused = h->lean_fused >= 0 ? h->lean_fused : (nblk <= 4 ? 1 : 0);
-    // Two block columns per pair of launches, 1024-thread workgroups (k_pair_step / k_pair_trsm): option lean_pair
-    const int want_pair = h->lean_pair >= 0 ? h->lean_pair : 0;
-    const int pair = (rl && want_pair && nblk >= 2) ? 1 : 0;
-    const int fused = (rl && !pair && !lazy && want_fused) ? 1 : 0;
+    const int fused = (rl && !lazy && want_fused) ? 1 : 0;
     h->lean_y = fused != 0;
     if (fused && (rc = h->ybuf.reserve((size_t)nh * Np * 8))) return rc;
     for (int k = 0; k < nblk + fused; ++k) {
-        if (pair) {
-            if (k & 1) continue;
-            TIMED(ST_CHOL_DIAG, launch_pair_step(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), Np, k, nh));
-            TIMED(ST_CHOL_PANEL, launch_pair_trsm(s, h->Lm.d(), h->Dinv.d(), rhs, Np, k, nh));
-        } else if (fused) {
+        if (fused) {
             TIMED(ST_CHOL_DIAG, launch_lean_fused(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), h->ybuf.d(), Np, k, nh));
         } else if (rl) {
             TIMED(ST_CHOL_DIAG, launch_lean_step(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), Np, k, nh, lazy));
