@@ -225,7 +225,7 @@ class GPEIBase(object):
         # what lets the sampler plan its speculative batches: where the log-probability is -inf whatever the data
         # say, and how the two ends of the bracket behaved in this chooser's earlier moves of the same kind
         many.admissible = lambda x: to_row(x) is not None
-        many.history = self.__dict__.setdefault("_slice_hist", {}).setdefault(kind, {"lo": [1.0, 1.0, 0.0], "hi": [1.0, 1.0, 0.0]})
+        many.history = self.__dict__.setdefault("_slice_hist", {}).setdefault(kind, {})
         return many
 
     # -- hyper-parameter sampling (host; GPEIChooser.py:268-346) -----------------
@@ -278,7 +278,7 @@ class GPEIBase(object):
 
     def _draw_ls(self, comp, vals, mean, amp2, noise, ls, max_ls):
         def inside(cand_ls):
-            return not (np.any(cand_ls < 0) or np.any(cand_ls > max_ls))
+            return not ((cand_ls < 0).any() or (cand_ls > max_ls).any())
 
         def logprob(cand_ls):
             if not inside(cand_ls):

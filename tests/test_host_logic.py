@@ -285,7 +285,7 @@ def test_speculative_sampler_is_the_same_markov_chain(golden_dir):
                     delattr(counting, attr)
             if with_adm:
                 counting.admissible = lambda x: not (np.any(x < 0) or np.any(x > 2))
-                counting.history = {"lo": [1.0, 1.0, 0.0], "hi": [1.0, 1.0, 0.0]}
+                counting.history = {}
             npr.seed(12); b = [np.ones(3)]
             for _ in range(40):
                 b.append(util.slice_sample_batched(b[-1], counting, sigma=sigma, compwise=compwise, lookahead=la))
@@ -312,7 +312,7 @@ def test_speculative_sampler_is_the_same_markov_chain(golden_dir):
                 delattr(many_push, attr)
         if with_adm:
             many_push.admissible = lambda x: not (np.any(x < 0) or np.any(x > 2))
-            many_push.history = {"lo": [1.0, 1.0, 0.0], "hi": [1.0, 1.0, 0.0]}
+            many_push.history = {}
         many_push.n = 0
         npr.seed(5); b = [np.ones(4)]
         for _ in range(60):
