@@ -178,6 +178,18 @@ __device__ __forceinline__ d4 inv_partial(const double* S, const double* XT, int
 }
 // X_ij = -Linv16_i t4: into XT (transposed, for the products of the rows below) and straight to Dk (row-major
 // [64][64]) from the registers of the wave that computed it
+// A store other workgroups of the SAME launch read (k_lean_step_ps hands the inverse of the diagonal block to the
+// panel workgroups while it is being built): relaxed, agent scope = a write-through `sc1` store, visible at the
+// device's coherence point once the issuing wave's vmcnt reaches zero (MI355X_MICROARCH.md, inter-workgroup
+// visibility: "8-B agent atomics both sides").
+template <bool PUB>
+__device__ __forceinline__ void dk_store(double* p, double v)
+{
+    if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <bool PUB>
 __device__ __forceinline__ void inv_finish(const d4& t4, double* XT, const double* T16, double* __restrict__ Dk,
                                            int i, int j, int g, int li)
 {
@@ -188,8 +200,9 @@ __device__ __forceinline__ void inv_finish(const d4& t4, double* XT, const doubl
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
-        Dk[(16 * i + g + 4 * r) * NB + 16 * j + li] = o4[r];
+        dk_store<PUB>(Dk + (16 * i + g + 4 * r) * NB + 16 * j + li, o4[r]);
     }
+    if (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drained before the barrier that precedes the flag
 }
 
 // S(ti,tj) -= P_ti P_tj^T with the sub-panel tiles of column b
@@ -214,9 +227,13 @@ __shared__ long long g_stamp[32];
 #else
 #define STAMP(i)
 #endif
+// PUB: block row b of the inverse (X_b0 .. X_bb) is published to the other workgroups of the launch as soon as it is
+// complete -- write-through stores, drained, then *flag = b + 1 (after the barrier that follows the last store of the
+// row) -- so that the panel solve of this block column proceeds behind the pivots instead of behind a launch boundary.
+template <bool PUB = false>
 __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, int* info_h, int pivot_base,
                                            double* __restrict__ Lkk, size_t ldl, double* __restrict__ Dk,
-                                           double* __restrict__ diag_out = nullptr)
+                                           double* __restrict__ diag_out = nullptr, int* flag = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -259,7 +276,17 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                     if ((idx++ % 3) == wave - 1) trail_tile(S, ti, tj, b0 - 16, g, li);
                 }
             // row b-1 of the inverse: wave j + 1 owns block column j (all X_pj of a column come from one wave)
-            if (wave - 1 < b - 1) inv_finish(inv_partial(S, XT, b - 1, wave - 1, g, li), XT, T16, Dk, b - 1, wave - 1, g, li);
+            if (wave - 1 < b - 1) inv_finish<PUB>(inv_partial(S, XT, b - 1, wave - 1, g, li), XT, T16, Dk, b - 1, wave - 1, g, li);
+            if (wave == 3) {
+                // the diagonal block of row b-1 of the inverse, from T16 to global memory -- here, where waves 1-3 have
+                // slack, not by wave 0 from its registers (four global stores in the critical wave cost ~200 cycles per
+                // round) and not in phase 2 (whose barrier would wait for the stores to drain when they are published)
+                const double* Tp = T16 + (b - 1) * 16 * 18;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dk_store<PUB>(Dk + (b0 - 16 + g + 4 * r) * NB + b0 - 16 + li, Tp[(g + 4 * r) * 18 + li]);
+                if (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             // while wave 0 factors the last sub-block: the inner sum of the LAST row, so that only the product
             // with Linv16_3 is left behind the last pivot (reads this wave's own XT stores: same wave, in order)
             if (b == 3) t4 = inv_partial(S, XT, 3, wave - 1, g, li);
@@ -267,6 +294,8 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         STAMP(1 + 4 * b);
         __syncthreads();
         STAMP(2 + 4 * b);
+        // block row b - 1 of the inverse is complete and drained: publish rows 0 .. b - 1
+        if (PUB && b >= 1 && threadIdx.x == 192) __hip_atomic_store(flag, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- phase 2: sub-panel, rows of tile ti = b+1+wave: P <- P Linv16^T ----
         {
             const int ti = b + 1 + wave;
@@ -280,11 +309,6 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + b0 + li] = c4[r];
-            } else if (wave == 3) {
-                // (wave 3 never has a sub-panel tile) the inverse's diagonal block, from T16 to global memory -- not by
-                // wave 0 from its registers: four global stores in the critical wave cost ~200 cycles per round
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Dk[(b0 + g + 4 * r) * NB + b0 + li] = Tb[(g + 4 * r) * 18 + li];
             }
         }
         if (b < 3) __syncthreads();   // round 3 has no sub-panel: nothing was written
@@ -297,7 +321,16 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         if (*info_h == 0) *info_h = bad;
     }
     // last row of the inverse: one product with Linv16_3 per block (rows 0-2 went out as they were built)
-    if (wave > 0 && wave < 4) inv_finish(t4, XT, T16, Dk, 3, wave - 1, g, li);
+    if (wave == 3) {         // the last diagonal block of the inverse
+        const double* Tp = T16 + 3 * 16 * 18;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dk_store<PUB>(Dk + (48 + g + 4 * r) * NB + 48 + li, Tp[(g + 4 * r) * 18 + li]);
+    }
+    if (wave > 0 && wave < 4) inv_finish<PUB>(t4, XT, T16, Dk, 3, wave - 1, g, li);
+    if (PUB) {   // the last block row
+        __syncthreads();
+        if (threadIdx.x == 192) __hip_atomic_store(flag, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     STAMP(17);
     // L_kk (upper part zero), 16 bytes per lane (S is complete since the last barrier); the log-likelihood path
     // only needs its diagonal (diag_out)
@@ -574,6 +607,128 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, d
         store_tile(row + (size_t)j * LEAN_TILE, acc);
         __syncthreads();               // B is rewritten for the next tile
     }
+}
+
+// k_lean_step_ps: k_lean_step with the PANEL SOLVE of block column k inside the same launch -- one launch per block
+// column, and unlike k_lean_fused no redundant products.  The workgroup that owns the first chunk of block row i > k
+// (and of the right-hand-side rows) keeps its updated tile (i,k) and, once its chunk is done, forms
+//     L_ik = R_ik Dinv_k^T
+// block column by block column of the result, BEHIND the pivots of the diagonal workgroup: diag_block<true> publishes
+// block row b of Dinv_k (write-through stores, drained, then a flag) as soon as it is complete -- three of the four
+// rows before the last 16 pivots have run -- and out columns 16 b .. 16 b + 15 need exactly the rows 0 .. b.  What is
+// left behind the last pivot is a flag hand-off, a 6 KB read and a quarter of a tile product, instead of a launch
+// boundary, a 64 KB read and a whole one.  The products skip the structurally zero upper blocks of Dinv_k (adding
+// exact zeros: same bits as k_lean_trsm).  One lane per waiting workgroup polls (relaxed agent-scope load + s_sleep,
+// bounded); the diagonal workgroups are the first of the grid, so they are resident before anyone waits for them.
+// flags: [nh][nblk] ints, zeroed by the caller.
+#define PS_SPIN_LIMIT (1 << 22)
+
+__global__ __launch_bounds__(256, 2) void k_lean_step_ps(double* __restrict__ Lt, double* __restrict__ Dinv,
+                                                      int* __restrict__ info, double* __restrict__ rhs,
+                                                      double* __restrict__ diagL, int* __restrict__ flags, int Np, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;              // [64][LDP]  L_i,k-1; then S (diagonal workgroup) / R_ik (panel solve)
+    double* B = smem + NB * LDP;   // [64][LDP]  L_j,k-1; then XT / the published rows of Dinv_k
+    double* T16 = B + NB * LDP;    // [4][16][18]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x;      // draws on x: the diagonal workgroups of all draws are dispatched first
+    const int nblk = Np / NB;
+    const bool is_rhs = blockIdx.y == gridDim.y - 1;
+    const int i = k + blockIdx.y;
+    const int j0 = k + blockIdx.z * LEAN_CH;
+    const int j1 = (k == 0) ? j0 + 1 : min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);   // k = 0: nothing to apply, tile (i,0) only
+    if (j0 >= j1) return;
+    double* Lh = Lt + (size_t)h * Np * Np;
+    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
+    double* Dk = Dinv + ((size_t)h * nblk + k) * NB * NB;
+    int* flag = flags + (size_t)h * nblk + k;
+    const bool solves = (j0 == k) && (is_rhs || i > k);      // this workgroup owns tile (i,k): it solves it too
+    const int kp = k > 0 ? k - 1 : 0;
+    d4 acc[4], accn[4], tb[4], rk[4];
+    load_tile(row + (size_t)j0 * LEAN_TILE, accn);
+    if (k > 0) {
+        load_tile(Lh + ((size_t)j0 * nblk + kp) * LEAN_TILE, tb);
+        d4 ta[4];
+        load_tile(row + (size_t)kp * LEAN_TILE, ta);
+        acc_tile_to_lds(ta, A, wave, g, li);      // the row operand, once
+    }
+    for (int j = j0; j < j1; ++j) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = accn[nt];
+        if (k > 0) {
+            acc_tile_to_lds(tb, B, wave, g, li);
+            __syncthreads();
+            if (j + 1 < j1) {              // the next tile's operand and accumulator fly while this one computes
+                load_tile(Lh + ((size_t)(j + 1) * nblk + kp) * LEAN_TILE, tb);
+                load_tile(row + (size_t)(j + 1) * LEAN_TILE, accn);
+            }
+            mma_tile_64(A, B, acc, wave, g, li, true);
+        }
+        if (!is_rhs && i == k && j == k) {
+            // the serial part of the factorisation (this is the only tile of this workgroup)
+            __syncthreads();           // every wave is done reading A / B
+            acc_tile_to_lds(acc, A, wave, g, li);
+            __syncthreads();
+            diag_block<true>(A, B, T16, info + h, k * NB, nullptr, 0, Dk, diagL + (size_t)h * Np + (size_t)k * NB, flag);
+            return;
+        }
+        if (solves && j == k) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) rk[nt] = acc[nt];       // R_ik stays here; its tile is written once, solved
+        } else if (k > 0) {
+            store_tile(row + (size_t)j * LEAN_TILE, acc);
+        }
+        if (k > 0) __syncthreads();    // B is rewritten for the next tile
+    }
+    if (!solves) return;
+    // ---- panel solve of tile (i,k), block column by block column, behind the diagonal workgroup ----
+    acc_tile_to_lds(rk, A, wave, g, li);
+    d4 out[4];
+    for (int b = 0; b < 4; ++b) {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= b && ++spins < PS_SPIN_LIMIT)
+                __builtin_amdgcn_s_sleep(8);
+            if (spins >= PS_SPIN_LIMIT && info[h] == 0) info[h] = -1;   // never on a healthy device: not a hang, an error
+        }
+        __syncthreads();
+        // rows 16 b .. 16 b + 15 of Dinv_k, columns 0 .. 16 b + 15, past this CU's L1 (the producer wrote them through)
+        // (16 x 16 (b + 1) doubles = b + 1 per thread; all loads in flight before the first LDS store)
+        double dv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m <= b) {
+                const int e = threadIdx.x + 256 * m;
+                dv[m] = __hip_atomic_load(Dk + (16 * b + e / (16 * (b + 1))) * NB + e % (16 * (b + 1)), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m <= b) {
+                const int e = threadIdx.x + 256 * m;
+                B[(16 * b + e / (16 * (b + 1))) * LDP + e % (16 * (b + 1))] = dv[m];
+            }
+        __syncthreads();
+        out[b] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < 16 * (b + 1); k0 += 4)
+            out[b] = MFMA_F64(A[(16 * wave + li) * LDP + k0 + g], B[(16 * b + li) * LDP + k0 + g], out[b]);
+    }
+    store_tile(row + (size_t)k * LEAN_TILE, out);
+}
+
+void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* flags,
+                         int Np, int k, int nh)
+{
+    const int n = Np / NB - k;
+    if (n <= 0) return;
+    const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step_ps),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // rows k .. nblk-1 and the right-hand-side rows; k = 0 has nothing to apply: one chunk (tile (i,0)) per row
+    const dim3 grid(nh, n + 1, k == 0 ? 1 : (n + LEAN_CH - 1) / LEAN_CH);
+    hipLaunchKernelGGL(k_lean_step_ps, grid, dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, flags, Np, k);
 }
 
 // k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile right of block column k (which needs

@@ -53,6 +53,8 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
 void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int Np, int k,
                       int nh, int lazy);
 void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs, int Np, int k, int nh);
+void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* flags,
+                         int Np, int k, int nh);
 void launch_lean_fused(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, double* ybuf,
                        int Np, int k, int nh);
 void launch_lean_logprob_y(hipStream_t s, const double* diagL, const double* ybuf, const int* info, double* out, int N,

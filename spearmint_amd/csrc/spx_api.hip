@@ -136,7 +136,7 @@ void spx_destroy(spx_handle* h)
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
                           &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
-                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ybuf,
+                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ybuf, &h->ps_flags,
                           &h->alphaS, &h->pt_u, &h->rec_send, &h->rec_recv, &h->rec_out, &h->ei_sum_full};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -172,6 +172,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_lazy")) {   // log-likelihood path: trailing updates two steps at a time (1), one (0), by size (-1, default)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "lean_ps")) {     // log-likelihood path: panel solve pipelined inside the step launch (1, default), separate launch (0)
+        h->lean_ps = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
     if (!strcmp(name, "lean_fused")) {  // log-likelihood path: one launch per block column (1), step + panel solve (0), by size (-1, default)
@@ -343,16 +347,28 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
     const int lazy = h->lean_lazy >= 0 ? h->lean_lazy : ((double)nh * Np * Np * 4.0 > 300e6 ? 1 : 0);
     // One launch per block column (k_lean_fused: every workgroup forms the panel operands it needs itself) unless the
     // batch is large enough for the lazy two-column updates; same factor, bit for bit.
-    // Measured (scripts/time_lean.py): the fused form wins where the launch count dominates (N <= 256: 0.178 vs 0.199 ms of
-    // kernels per call) and loses from N = 1024 on (one draw at N = 2048: 30.7 vs 28.1 us per block column; 8 draws 1.80
-    // vs 1.33 ms) -- its MFMA-heavy workgroups share SIMDs with the wave that runs the pivots -- so by default it is
-    // chosen by size (option lean_fused = -1); 0 / 1 force either form.
+    // Measured (scripts/time_lean.py): the fused form wins over step + panel-solve launches where the launch count
+    // dominates (N <= 256: 0.178 vs 0.199 ms of kernels per call) and loses from N = 1024 on (one draw at N = 2048: 30.7 vs
+    // 28.1 us per block column; 8 draws 1.80 vs 1.33 ms) -- its MFMA-heavy workgroups share SIMDs with the wave that runs
+    // the pivots; k_lean_step_ps below beats both from four block columns up.  By default chosen by size (option
+    // lean_fused = -1); 0 / 1 force either form (when lean_ps does not apply).
     const int want_fused = h->lean_fused >= 0 ? h->lean_fused : (nblk <= 4 ? 1 : 0);
-    const int fused = (rl && !lazy && want_fused) ? 1 : 0;
+    // Panel solve inside the step launch, pipelined behind the diagonal block's pivots (k_lean_step_ps): option lean_ps
+    // (measured, scripts/dev/lean_option_ab.py: -1 ... -8 % per call from N = 256 up -- 2048: -6.5 % at 4-12 draws, -1 % at
+    // one; 1000: -3 ... -13 %; 4096: -4 ... -5 % -- and no gain over k_lean_fused at two block columns)
+    const int want_ps = h->lean_ps >= 0 ? h->lean_ps : (nblk > 2 ? 1 : 0);
+    const int ps = (rl && !lazy && want_ps) ? 1 : 0;
+    const int fused = (rl && !ps && !lazy && want_fused) ? 1 : 0;
+    if (ps) {
+        if ((rc = h->ps_flags.reserve((size_t)nh * nblk * sizeof(int)))) return rc;
+        HIPCHK(hipMemsetAsync(h->ps_flags.p, 0, (size_t)nh * nblk * sizeof(int), s));
+    }
     h->lean_y = fused != 0;
     if (fused && (rc = h->ybuf.reserve((size_t)nh * Np * 8))) return rc;
     for (int k = 0; k < nblk + fused; ++k) {
-        if (fused) {
+        if (ps) {
+            TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));
+        } else if (fused) {
             TIMED(ST_CHOL_DIAG, launch_lean_fused(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), h->ybuf.d(), Np, k, nh));
         } else if (rl) {
             TIMED(ST_CHOL_DIAG, launch_lean_step(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), Np, k, nh, lazy));
@@ -383,6 +399,9 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
         h->st_ms[ST_FACTOR_TOTAL] += ms; h->st_n[ST_FACTOR_TOTAL] += 1;
     }
     h->not_pd_draw = h->not_pd_pivot = -1;
+    for (int i = 0; i < nh; ++i)
+        if (info[i] < 0)   // k_lean_step_ps: a panel workgroup gave up waiting for the diagonal block (bounded spin)
+            return fail(SPX_ERR_HIP, "log-likelihood factorisation: in-launch hand-off timed out (draw %d)", i);
     for (int i = 0; i < nh; ++i)
         if (info[i]) { h->not_pd_draw = i; h->not_pd_pivot = info[i] - 1; break; }
     h->factored = !lean;
