@@ -93,7 +93,7 @@ def pmc_traffic(workload):
     same command (profiles/r0X_<workload>_rocprof_summary.json, written by
     scripts/pmc_summary.py: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE
     doubled per the gfx950 correction of MI355X_MICROARCH.md).  None when no profile exists."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_rocprof_summary.json" % (rnd, workload))
         try:
             with open(path) as fh:
