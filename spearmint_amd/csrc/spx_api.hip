@@ -267,7 +267,11 @@ int spx_set_time_model(spx_handle* h, const double* log_durs, const double* time
 }
 
 // ---------------------------------------------------------------------------
-static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
+static int finish_factor(spx_handle* h, const std::vector<int>& info, bool tolerate_not_pd, bool lean);
+
+// defer_sync (log-likelihood path): return with the work queued -- the caller adds its own kernel, copies `info` back
+// together with its result, synchronises ONCE and calls finish_factor (one host round trip per call instead of two)
+static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, bool defer_sync = false)
 {
     if (!h->have_obs || !h->have_hyp)
         return fail(SPX_ERR_ARG, "spx_factor: observations and hypers must be set first");
@@ -388,12 +392,19 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false)
         TIMED(ST_GAMMA_ALPHA, launch_alpha(s, h->WT.d(), h->gamma.d(), h->alpha.d(), Np, nh));
     }
     HIPCHK(hipEventRecord(t1, s));
+    if (defer_sync) return SPX_OK;
     std::vector<int> info(nh);
     HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)nh * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return finish_factor(h, info, tolerate_not_pd, lean);
+}
+
+static int finish_factor(spx_handle* h, const std::vector<int>& info, bool tolerate_not_pd, bool lean)
+{
+    const int nh = (int)info.size(), H = h->H;
     HIPCHK(hipGetLastError());
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1);
     if (h->timing) {
         ev_collect(h);
         h->st_ms[ST_FACTOR_TOTAL] += ms; h->st_n[ST_FACTOR_TOTAL] += 1;
@@ -773,7 +784,7 @@ int spx_gp_logprob(spx_handle* h, double* out)
 {
     if (!h || !out) return fail(SPX_ERR_ARG, "spx_gp_logprob: null");
     if (h->multi) return spx_multi_gp_logprob(h->multi, out);
-    int rc = do_factor(h, true, true);   // K(X,X), Cholesky, forward solve -- no inverse
+    int rc = do_factor(h, true, true, true);   // K(X,X), Cholesky, forward solve -- no inverse; queued, not yet synchronised
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
     if (h->lean_tiled && h->lean_y)
@@ -782,9 +793,11 @@ int spx_gp_logprob(spx_handle* h, double* out)
         launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, h->lp.d(), (int)h->N, h->Np, h->H);
     else
         launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);
+    std::vector<int> info(h->H);
     HIPCHK(hipMemcpyAsync(out, h->lp.p, (size_t)h->H * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)h->H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return SPX_OK;
+    return finish_factor(h, info, true, true);
 }
 
 static int run_grid(spx_handle* h, const double* comp, const double* vals, const double* log_durs,

@@ -3,9 +3,10 @@
 chooser modules on the real `libspx.so`.
 
 `__graft_entry__.build()` converts the reference's driver for Python 3 (stdlib
-lib2to3 + the import rewrite of SURVEY.md Appendix D, nothing else) into
-`oracle/_ref/lite/` where /root/reference exists; that directory is git-ignored but
-travels to the GPU box with the tree, like a built .so.  Here its unmodified
+lib2to3 + the import rewrite of SURVEY.md Appendix D, nothing else) into the archive
+`oracle/_ref/lite_py3.zip` where /root/reference exists; the archive is git-ignored but
+travels to the GPU box with the tree, like a built .so, and is unpacked here into a
+temporary directory.  Its unmodified
 `main_controller` is run with `dropin/` on the path -- `--method=GPEIChooser |
 GPEIOptChooser | GPEIperSecChooser` resolves to OUR modules -- for seven proposals each,
 the last two in ONE call so that the second sees the first as a pending job, and the
@@ -14,19 +15,19 @@ the two results files must hold the same proposals.
 """
 import importlib
 import os
-import shutil
 import sys
 import types
+import zipfile
 
 import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LITE = os.path.join(ROOT, "oracle", "_ref", "lite")
+LITE_ZIP = os.path.join(ROOT, "oracle", "_ref", "lite_py3.zip")
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.isfile(os.path.join(LITE, "spearmint_lite_main.py")),
-                                 reason="oracle/_ref/lite absent: run __graft_entry__.build() where /root/reference "
+              pytest.mark.skipif(not os.path.isfile(LITE_ZIP),
+                                 reason="oracle/_ref/lite_py3.zip absent: run __graft_entry__.build() where /root/reference "
                                         "exists (it converts the reference's spearmint-lite driver)")]
 
 _LITE_MODULES = ("spearmint_lite_main", "ExperimentGrid", "sobol_lib", "Locker", "util")
@@ -109,7 +110,8 @@ def test_reference_lite_loop_on_libspx_equals_oracle_engine(tmp_path, method, ma
     runs = {}
     for tag, factory in (("gpu", None), ("oracle", OracleEngine)):
         work = str(tmp_path / tag)
-        shutil.copytree(LITE, work)
+        with zipfile.ZipFile(LITE_ZIP) as z:
+            z.extractall(work)
         runs[tag] = _run_loop(work, method, margs, 11, factory)
     gpu_lines, gpu_engines = runs["gpu"]
     ora_lines, _ = runs["oracle"]
