@@ -590,3 +590,42 @@ def test_opt_chooser_rescore_grid_does_not_change_the_proposal(tmp_path, npend, 
         assert isinstance(j1, tuple) and j0[0] == j1[0] and np.array_equal(j0[1], j1[1])
     else:
         assert j0 == j1
+
+
+def test_in_launch_handoff_under_concurrent_load(eng):
+    """k_lean_step_ps hands the inverse of every diagonal block to the panel workgroups inside the launch (write-through
+    stores, drained, then a flag; readers past their L1).  A stale read would show as different bits -- looked for here
+    under UNEVEN load: a second engine keeps the GPU busy with EI grids from another host thread while random sizes and
+    batch sizes go through the hand-off repeatedly; the two-launch path is the reference, bit for bit."""
+    import threading
+    from spearmint_amd.engine import Engine
+    stop = []
+
+    def noise():
+        e2 = Engine(0)
+        comp, cand, vals, hyp = synthetic_problem(700, 20000, 9, 5, 199)
+        while not stop:
+            e2.ei_grid(comp, vals, cand, hyp, want_mean=False)
+        e2.close()
+    th = threading.Thread(target=noise)
+    th.start()
+    rs = np.random.RandomState(17)
+    try:
+        for _ in range(40):
+            N = int(rs.choice([260, 330, 700, 1000, 1500, 2048]))
+            H = int(rs.randint(1, 25))
+            comp, cand, vals, hyp = synthetic_problem(N, 10, int(rs.choice([2, 8, 32])), H, int(rs.randint(1 << 30)))
+            if rs.rand() < 0.25:
+                hyp[rs.randint(H), 2] = -1.0             # a non-PD draw: its workgroups must not hold the others up
+            eng.set_observations(comp, vals)
+            eng.set_option("lean_ps", 0)
+            eng.set_hypers(hyp)
+            ref = eng.gp_logprob()
+            eng.set_option("lean_ps", 1)
+            for rep in range(5):
+                eng.set_hypers(hyp)
+                assert np.array_equal(eng.gp_logprob(), ref), (N, H, rep)
+    finally:
+        stop.append(1)
+        th.join()
+        eng.set_option("lean_ps", -1)
