@@ -226,9 +226,12 @@ const char* spx_timing_name(int i);
 #define SPX_COVAR_SE       3   /* gp.SE       (gp.py:87-93): ARDSE with the length scales ignored */
 /* options: "covar" (SPX_COVAR_*); tuning knobs "kstar_budget_bytes" (K(X*,X) staging buffer;
  * 0 = default), "streams" (1|2), "timing" (0|1), "gemm_waves" (predict-GEMM variant of THIS
- * handle; values the build does not contain are rejected with SPX_ERR_ARG), "lean_lazy"
- * (log-likelihood path: trailing updates one (0) or two (1) block columns at a time, -1 = chosen
- * from the batch size; results are bit-identical either way).                                  */
+ * handle; values the build does not contain are rejected with SPX_ERR_ARG), and the forms of the
+ * log-likelihood factorisation, all bit-identical, -1 = chosen from the sizes: "lean_lazy" (trailing
+ * updates one (0) or two (1) block columns at a time), "lean_ps" (1: the panel solve of a block column
+ * runs inside the update launch, handed the inverse of the diagonal block behind its pivots; 0: a
+ * launch of its own), "lean_fused" (1: one launch per block column with redundantly formed panel
+ * operands; applies where lean_ps does not).                                                     */
 int spx_set_option(spx_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus
