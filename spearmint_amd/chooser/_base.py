@@ -184,7 +184,7 @@ class GPEIBase(object):
         lp = eng.gp_logprob()
         return lp, np.isneginf(lp)
 
-    def _speculative_logprob(self, comp, vals, to_row, finish, kind="ls"):
+    def _speculative_logprob(self, comp, vals, to_row, finish, kind="ls", admissible=None):
         """Adapter for util.slice_sample_batched: `to_row(x)` gives the hyper row to evaluate or
         None when x is rejected a priori (-inf without touching the GP, as the reference's
         closures do); `finish(x, data_lp)` adds the priors."""
@@ -224,7 +224,7 @@ class GPEIBase(object):
             return util._LazyValues(values, errors)
         # what lets the sampler plan its speculative batches: where the log-probability is -inf whatever the data
         # say, and how the two ends of the bracket behaved in this chooser's earlier moves of the same kind
-        many.admissible = lambda x: to_row(x) is not None
+        many.admissible = admissible if admissible is not None else (lambda x: to_row(x) is not None)
         many.history = self.__dict__.setdefault("_slice_hist", {}).setdefault(kind, {})
         return many
 
@@ -270,7 +270,8 @@ class GPEIBase(object):
             def to_row(h):
                 ok = admissible(h)
                 return None if ok is None else np.concatenate(([ok[0], ok[2], ok[1]], ls))
-            new = util.slice_sample_batched(start, self._speculative_logprob(comp, vals, to_row, priors, kind="joint"),
+            new = util.slice_sample_batched(start, self._speculative_logprob(comp, vals, to_row, priors, kind="joint",
+                                                                             admissible=lambda h: admissible(h) is not None),
                                             compwise=False, lookahead=self.lookahead)
         else:
             new = util.slice_sample(start, logprob, compwise=False)
@@ -288,7 +289,8 @@ class GPEIBase(object):
         if self._use_gpu_logprob(comp.shape[0]):
             def to_row(cand_ls):
                 return np.concatenate(([mean, noise, amp2], cand_ls)) if inside(cand_ls) else None
-            return util.slice_sample_batched(ls, self._speculative_logprob(comp, vals, to_row, lambda x, lp: lp),
+            return util.slice_sample_batched(ls, self._speculative_logprob(comp, vals, to_row, lambda x, lp: lp,
+                                                                           admissible=inside),
                                              compwise=True, lookahead=self.lookahead)
         return util.slice_sample(ls, logprob, compwise=True)
 
