@@ -1048,12 +1048,18 @@ void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs
 }
 
 // the right-hand-side block row in tile storage: row 0 = vals - mean (0 for pad entries), rows 1..63 = 0
+// (also zeroes the draw's not-PD flag and, for k_lean_step_ps, its hand-off flags: two memsets fewer per call)
 __global__ __launch_bounds__(256) void k_lean_rhs_init(const double* __restrict__ vals,
                                                        const double* __restrict__ htab,
-                                                       double* __restrict__ rhs, int N, int Np)
+                                                       double* __restrict__ rhs, int N, int Np,
+                                                       int* __restrict__ info, int* __restrict__ flags)
 {
     const int h = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;      // over [nblk][4096]
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) info[h] = 0;
+        if (flags && threadIdx.x < Np / NB) flags[h * (Np / NB) + threadIdx.x] = 0;
+    }
     if (idx >= NB * Np) return;
     const int J = idx >> 12, e = idx & 4095;
     const int t = (e >> 1) & 255, q = ((e >> 9) << 1) | (e & 1);   // thread slot, value q = nt * 4 + r
@@ -1064,9 +1070,10 @@ __global__ __launch_bounds__(256) void k_lean_rhs_init(const double* __restrict_
     rhs[(size_t)h * NB * Np + idx] = v;
 }
 
-void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh)
+void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh,
+                          int* info, int* flags)
 {
-    hipLaunchKernelGGL(k_lean_rhs_init, dim3((NB * Np + 255) / 256, nh), dim3(256), 0, s, vals, htab, rhs, N, Np);
+    hipLaunchKernelGGL(k_lean_rhs_init, dim3((NB * Np + 255) / 256, nh), dim3(256), 0, s, vals, htab, rhs, N, Np, info, flags);
 }
 
 // lp = -sum log diag(L) - 0.5 |y|^2 (GPEIChooser.py:284) from the diagonal the diag blocks left in diagL

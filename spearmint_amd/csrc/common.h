@@ -59,7 +59,8 @@ void launch_lean_fused(hipStream_t s, double* Lt, double* Dinv, int* info, doubl
                        int Np, int k, int nh);
 void launch_lean_logprob_y(hipStream_t s, const double* diagL, const double* ybuf, const int* info, double* out, int N,
                            int Np, int nh);
-void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh);
+void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh,
+                          int* info, int* flags);
 void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int N,
                          int Np, int nh);
 void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh);

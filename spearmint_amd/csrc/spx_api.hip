@@ -286,7 +286,11 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     const int hs = 3 + D;
 
     // host-side hyper tables: raw rows (for ls) and [mean, noise, amp2, amp2*(1+1e-6)]
-    std::vector<double> raw((size_t)nh * hs), tab((size_t)nh * SPX_HT);
+    // (members, not locals: the log-likelihood path returns before it synchronises, and the upload must not outlive its source)
+    std::vector<double>& raw = h->up_raw;
+    std::vector<double>& tab = h->up_tab;
+    raw.assign((size_t)nh * hs, 0.0);
+    tab.assign((size_t)nh * SPX_HT, 0.0);
     for (int m = 0; m < nm; ++m) {
         const std::vector<double>& src = m ? h->thyp_host : h->hyp_host;
         for (int i = 0; i < H; ++i) {
@@ -299,8 +303,10 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
             t[3] = r[2] * (1 + 1e-6);  // self.amp2*(1+1e-6), GPEIChooser.py:199
         }
     }
+    // raw rows and the table travel in ONE upload: htab is a view of the tail of the hyp buffer
+    raw.insert(raw.end(), tab.begin(), tab.end());
     if ((rc = h->hyp.reserve(raw.size() * 8))) return rc;
-    if ((rc = h->htab.reserve(tab.size() * 8))) return rc;
+    h->htab.alias_of(h->hyp.d() + (size_t)nh * hs);
     const size_t nn = (size_t)nh * Np * Np;
     if ((rc = h->Xs.reserve((size_t)nh * Np * Dp * 8))) return rc;
     if ((rc = h->X2s.reserve((size_t)nh * Np * Dp * 8))) return rc;
@@ -316,9 +322,11 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     h->ev_used = 0;
     hipEvent_t t0 = h->ev_t0, t1 = h->ev_t1;
     HIPCHK(hipMemcpyAsync(h->hyp.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->htab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipEventRecord(t0, s));
-    HIPCHK(hipMemsetAsync(h->info.p, 0, (size_t)nh * sizeof(int), s));
+    if (h->timing || !lean) HIPCHK(hipEventRecord(t0, s));
+    // the log-likelihood path zeroes info (and the hand-off flags) in its right-hand-side kernel: two stream operations
+    // fewer per call
+    const bool zero_in_kernel = lean && nh <= 32;
+    if (!zero_in_kernel) HIPCHK(hipMemsetAsync(h->info.p, 0, (size_t)nh * sizeof(int), s));
     if (!lean) HIPCHK(hipMemsetAsync(h->WT.p, 0, nn * 8, s));
 
     const double* ls = h->hyp.d() + 3;
@@ -330,20 +338,6 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // diagonal block factored inside the update launch (k_lean_step); same accumulation order, same bits.
     const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
     TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, rl != 0, dev_kind(h)));
-    // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
-    // so y = L^-1 (vals - mean) is ready when the last column is
-    double* rhs = nullptr;
-    if (lean) {
-        if ((rc = h->rhs.reserve((size_t)nh * SPX_NB * Np * 8))) return rc;
-        rhs = h->rhs.d();
-        if (rl) {
-            if ((rc = h->diagL.reserve((size_t)nh * Np * 8))) return rc;
-            TIMED(ST_GAMMA_ALPHA, launch_lean_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh));
-        } else {
-            TIMED(ST_GAMMA_ALPHA, launch_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh));
-        }
-        h->lean_tiled = rl != 0;
-    }
     // Trailing updates two block columns at a time (k_lean_step2) halve the traffic of the trailing matrices but
     // put a second MFMA step in front of every other diagonal block; that pays once the lower triangles of the
     // batch no longer fit the 256 MB Infinity Cache (measured: N=2048 from ~20 draws, N=4096 from 6; -3 ... -16 %),
@@ -363,9 +357,21 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     const int want_ps = h->lean_ps >= 0 ? h->lean_ps : (nblk > 2 ? 1 : 0);
     const int ps = (rl && !lazy && want_ps) ? 1 : 0;
     const int fused = (rl && !ps && !lazy && want_fused) ? 1 : 0;
-    if (ps) {
-        if ((rc = h->ps_flags.reserve((size_t)nh * nblk * sizeof(int)))) return rc;
-        HIPCHK(hipMemsetAsync(h->ps_flags.p, 0, (size_t)nh * nblk * sizeof(int), s));
+    if (ps && (rc = h->ps_flags.reserve((size_t)nh * nblk * sizeof(int)))) return rc;   // zeroed by k_lean_rhs_init
+    // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
+    // so y = L^-1 (vals - mean) is ready when the last column is
+    double* rhs = nullptr;
+    if (lean) {
+        if ((rc = h->rhs.reserve((size_t)nh * SPX_NB * Np * 8))) return rc;
+        rhs = h->rhs.d();
+        if (rl) {
+            if ((rc = h->diagL.reserve((size_t)nh * Np * 8))) return rc;
+            TIMED(ST_GAMMA_ALPHA, launch_lean_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh, (int*)h->info.p,
+                                                       ps ? (int*)h->ps_flags.p : nullptr));
+        } else {
+            TIMED(ST_GAMMA_ALPHA, launch_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh));
+        }
+        h->lean_tiled = rl != 0;
     }
     h->lean_y = fused != 0;
     if (fused && (rc = h->ybuf.reserve((size_t)nh * Np * 8))) return rc;
@@ -391,7 +397,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
                                                 h->gamma.d() + (size_t)H * Np, (int)N, Np, H));
         TIMED(ST_GAMMA_ALPHA, launch_alpha(s, h->WT.d(), h->gamma.d(), h->alpha.d(), Np, nh));
     }
-    HIPCHK(hipEventRecord(t1, s));
+    if (h->timing || !lean) HIPCHK(hipEventRecord(t1, s));
     if (defer_sync) return SPX_OK;
     std::vector<int> info(nh);
     HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)nh * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -404,8 +410,8 @@ static int finish_factor(spx_handle* h, const std::vector<int>& info, bool toler
     const int nh = (int)info.size(), H = h->H;
     HIPCHK(hipGetLastError());
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1);
     if (h->timing) {
+        (void)hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1);
         ev_collect(h);
         h->st_ms[ST_FACTOR_TOTAL] += ms; h->st_n[ST_FACTOR_TOTAL] += 1;
     }

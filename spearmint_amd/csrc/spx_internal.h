@@ -29,8 +29,11 @@ int spx_fail(int code, const char* fmt, ...);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool owned = true;      // false: p points into another DevBuf (alias_of): never freed here
+    void alias_of(void* q) { if (p && owned) (void)hipFree(p); p = q; cap = 0; owned = false; }
     int reserve(size_t bytes)
     {
+        if (!owned) { p = nullptr; cap = 0; owned = true; }
         if (bytes <= cap) return SPX_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         hipError_t e = hipMalloc(&p, bytes);
@@ -42,7 +45,7 @@ struct DevBuf {
         cap = bytes;
         return SPX_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
     double* d() const { return (double*)p; }
 };
 
@@ -76,6 +79,7 @@ struct spx_handle {
     struct spx_comm* comm = nullptr;    // non-null: one-process-per-GPU communicator attached (spx_comm_attach)
 
     std::vector<double> hyp_host, thyp_host;
+    std::vector<double> up_raw, up_tab;     // host staging of the per-call hyper upload (do_factor)
 
     DevBuf comp, vals, ldur, cand, hyp, htab;
     DevBuf Xs, X2s, s1, Lm, WT, Dinv, gamma, alpha, info, lp;
