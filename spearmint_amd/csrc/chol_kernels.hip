@@ -994,7 +994,7 @@ void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double
 // operand fragments of a wave are a quarter as many LDS reads.  (It does NOT shorten the matrix-pipe time: a CU has
 // four matrix pipes, one per SIMD, and a 64x64x64 fp64 product is 256 v_mfma_f64_16x16x4 of 64 cycles each =
 // 1.7 us of a CU however many waves issue them -- measured in round 3 with the corner workgroup of a
-// two-columns-per-launch variant, scripts/dev/attic/chol_kernels_pair_columns.hip.txt.)
+// two-columns-per-launch variant, scripts/dev/attic/pair_columns_kernels.hip.txt.)
 __global__ __launch_bounds__(1024) void k_lean_trsm(double* __restrict__ Lt, const double* __restrict__ Dinv,
                                                     double* __restrict__ rhs, int Np, int k)
 {
