@@ -618,3 +618,39 @@ def test_multi_handle_state_after_a_sharded_loglikelihood_and_options(eng):
         assert me.best() == (one[0], one[1])
     finally:
         me.close()
+
+
+def test_rccl_transport_on_distinct_gpus(eng):
+    """the RCCL transport on MORE than one physical GPU (the 1-GPU test box skips this; the first multi-GPU box
+    that runs the suite checks it): ncclCommInitAll over the devices, ncclAllGather of the records, ncclAllReduce of the EI
+    sums in the 2-D partition -- bit-equal to the one-GPU handle."""
+    from spearmint_amd import engine as eng_mod
+    ndev = eng_mod.device_count()
+    if ndev < 2:
+        pytest.skip("needs at least two GPUs (found %d)" % ndev)
+    n = 4 if ndev >= 4 else 2
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(300, 20011, 6, 8, 123, per_sec=True)
+    one = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    ops = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+    me = MultiEngine(list(range(n)))
+    try:
+        assert me.transport() == "rccl"
+        many = me.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        assert many[0] == one[0] and many[1] == one[1]
+        assert np.array_equal(many[2], one[2]) and np.array_equal(many[3], one[3])
+        mps = me.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+        assert mps[0] == ops[0] and np.array_equal(mps[3], ops[3])
+        eng.set_observations(comp, vals); eng.set_hypers(hypers)
+        me.set_observations(comp, vals); me.set_hypers(hypers)
+        assert np.array_equal(me.gp_logprob(), eng.gp_logprob())       # draws sharded over the devices
+        # the 2-D partition: one ncclAllReduce(SUM) of the EI-sum vector over xGMI
+        me.set_partition(2)
+        me.set_hypers(hypers); me.set_candidates(cand); me.factor(); me.ei_run()
+        idx, mean, blocks = _emulate_2d(eng, comp, vals, cand, hypers, n, 2)
+        assert me.best()[0] == idx == one[0]
+        assert np.allclose(me.ei_mean(), mean, rtol=1e-14, atol=0)       # (the reduction tree's order for n = 4)
+        assert np.array_equal(me.ei_draws(), blocks)
+        if n == 2:
+            assert np.array_equal(me.ei_mean(), mean)
+    finally:
+        me.close()
