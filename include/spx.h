@@ -230,8 +230,7 @@ const char* spx_timing_name(int i);
  * log-likelihood factorisation, all bit-identical, -1 = chosen from the sizes: "lean_lazy" (trailing
  * updates one (0) or two (1) block columns at a time), "lean_ps" (1: the panel solve of a block column
  * runs inside the update launch, handed the inverse of the diagonal block behind its pivots; 0: a
- * launch of its own), "lean_fused" (1: one launch per block column with redundantly formed panel
- * operands; applies where lean_ps does not).                                                     */
+ * launch of its own).                                                                            */
 int spx_set_option(spx_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -5,8 +5,8 @@ import numpy as np
 from spearmint_amd.engine import Engine
 from spearmint_amd.synthetic import synthetic_problem
 eng = Engine(0)
-if os.environ.get('SPX_LEAN_FUSED'):
-    eng.set_option('lean_fused', int(os.environ['SPX_LEAN_FUSED']))
+if os.environ.get('SPX_LEAN_PS'):
+    eng.set_option('lean_ps', int(os.environ['SPX_LEAN_PS']))
 for N, D in ((2048, 32), (1024, 16), (256, 8)):
     for H in (1, 4, 8, 20):
         comp, cand, vals, hypers = synthetic_problem(N, 16, D, H, 5)

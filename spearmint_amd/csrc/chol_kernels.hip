@@ -610,7 +610,8 @@ __global__ __launch_bounds__(256, 2) void k_lean_step(double* __restrict__ Lt, d
 }
 
 // k_lean_step_ps: k_lean_step with the PANEL SOLVE of block column k inside the same launch -- one launch per block
-// column, and unlike k_lean_fused no redundant products.  The workgroup that owns the first chunk of block row i > k
+// column, no redundant products (a form in which every workgroup recomputed the panel operands it needs, k_lean_fused,
+// was measured and dropped: scripts/dev/attic).  The workgroup that owns the first chunk of block row i > k
 // (and of the right-hand-side rows) keeps its updated tile (i,k) and, once its chunk is done, forms
 //     L_ik = R_ik Dinv_k^T
 // block column by block column of the result, BEHIND the pivots of the diagonal workgroup: diag_block<true> publishes
@@ -788,179 +789,6 @@ __global__ __launch_bounds__(256, 2) void k_lean_step2(double* __restrict__ Lt, 
 #pragma unroll
     for (int c = 0; c < LEAN_CH; ++c)
         if (c < nc) store_tile(row + (size_t)(j0 + c) * LEAN_TILE, acc[c]);
-}
-
-// k_lean_fused: ONE launch per block column (small batches; the two-launch form above stays for lazy updates).
-// Launch k applies update step k-1 like k_lean_step, but no launch has solved the panel of column k-1: every
-// workgroup forms the operands it needs itself from the RAW panel tiles R_i,k-1 (complete but not yet multiplied
-// by L_k-1,k-1^-T) and the inverse of the diagonal block that launch k-1 left in Dinv,
-//     L_i,k-1 = R_i,k-1 Dinv_k-1^T ,
-// -- the same 64-deep MFMA chain per element as k_lean_trsm, so the factor keeps its bits.  What that buys: the
-// dependent chain of a block column is  launch -> (this tile's two operands) -> update -> diagonal block  instead
-// of  launch -> update -> diagonal block -> launch -> panel solve;  what it costs: a workgroup that walks nc tiles
-// of a block row multiplies 1 + 2 nc tile products instead of nc, which the matrix pipes have to spare while the
-// diagonal workgroup runs its pivots (one draw) and while the tile traffic binds (several draws).
-//   row operand:  each wave needs only ITS 16 rows of L_i,k-1 as MFMA A fragments.  It computes their transpose,
-//       (L_i^T)(16 b + n', 16 w + i) = sum_q Dinv[16 b + n'][q] R_i[16 w + i][q] ,
-//     whose accumulator layout (reg r of lane (c, q) = L_i[16 w + c][16 b + q + 4 r]) IS the A fragment of k-step
-//     16 b + 4 r: the row operand never goes through LDS, and two LDS tiles (Dinv; the column operand) keep two
-//     workgroups per CU.
-//   column operand: L_j,k-1 = R_j Dinv^T through LDS (every wave reads all of it).
-// The right-hand-side rows' solved blocks -- y, what the log-likelihood needs -- go to ybuf[h][Np] (row 0 of the
-// block): block k-1 in launch k, so the last launch is k = nblk with the right-hand-side workgroups only.
-__global__ __launch_bounds__(256, 2) void k_lean_fused(double* __restrict__ Lt, double* __restrict__ Dinv,
-                                                    int* __restrict__ info, double* __restrict__ rhs,
-                                                    double* __restrict__ diagL, double* __restrict__ ybuf,
-                                                    int Np, int k)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Dv = smem;              // [64][LDP]  Dinv_k-1 (row-major); the diagonal workgroup's XT afterwards
-    double* Bb = smem + NB * LDP;   // [64][LDP]  raw panel tile, then the column operand L_j,k-1; then S
-    double* T16 = Bb + NB * LDP;    // [4][16][18]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.x;       // draws on x: the diagonal workgroups of all draws are dispatched first
-    const int nblk = Np / NB;
-    const bool is_rhs = rhs && blockIdx.y == gridDim.y - 1;
-    const int i = k + blockIdx.y;
-    const int j0 = k + blockIdx.z * LEAN_CH;
-    const int j1 = min(j0 + LEAN_CH, is_rhs ? nblk : i + 1);
-    const bool want_y = is_rhs && blockIdx.z == 0;          // this workgroup publishes y block k-1
-    if (j0 >= j1 && !want_y) return;
-    double* Lh = Lt + (size_t)h * Np * Np;
-    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
-    d4 acc[4];
-    if (k == 0) {                   // nothing to apply: the diagonal block as cov left it
-        load_tile(row, acc);
-        acc_tile_to_lds(acc, Bb, wave, g, li);
-        __syncthreads();
-        diag_block(Bb, Dv, T16, info + h, 0, nullptr, 0, Dinv + (size_t)h * nblk * NB * NB, diagL + (size_t)h * Np);
-        return;
-    }
-    const int kp = k - 1;
-    d4 accn[4], rj[4], aT[4];
-    {
-        d4 ri[4];
-        load_tile(row + (size_t)kp * LEAN_TILE, ri);
-        if (j0 < j1) {
-            load_tile(row + (size_t)j0 * LEAN_TILE, accn);
-            load_tile(Lh + ((size_t)j0 * nblk + kp) * LEAN_TILE, rj);
-        }
-        tile_to_lds(Dinv + ((size_t)h * nblk + kp) * NB * NB, NB, Dv);
-        acc_tile_to_lds(ri, Bb, wave, g, li);
-    }
-    __syncthreads();
-    // this wave's rows of the row operand, transposed: aT[b][r] = L_i[16 wave + li][16 b + g + 4 r]
-#pragma unroll
-    for (int b = 0; b < 4; ++b) aT[b] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int k0 = 0; k0 < NB; k0 += 4) {
-        const double bv = Bb[(16 * wave + li) * LDP + k0 + g];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) aT[b] = MFMA_F64(Dv[(16 * b + li) * LDP + k0 + g], bv, aT[b]);
-    }
-    if (want_y && wave == 0 && li == 0) {      // row 0 of the right-hand-side block: y[64 (k-1) + 16 b + g + 4 r]
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ybuf[(size_t)h * Np + (size_t)kp * NB + 16 * b + g + 4 * r] = aT[b][r];
-    }
-    for (int j = j0; j < j1; ++j) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = accn[nt];
-        const bool same = (!is_rhs && j == i);      // the column operand is the row operand (diagonal tile)
-        d4 lj[4];
-        __syncthreads();                             // every wave is done with Bb (row operand / previous tile)
-        if (!same) acc_tile_to_lds(rj, Bb, wave, g, li);
-        if (j + 1 < j1) {                            // the next tile's panel tile and accumulator fly meanwhile
-            load_tile(Lh + ((size_t)(j + 1) * nblk + kp) * LEAN_TILE, rj);
-            load_tile(row + (size_t)(j + 1) * LEAN_TILE, accn);
-        }
-        if (!same) {
-            __syncthreads();
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) lj[nt] = (d4){0.0, 0.0, 0.0, 0.0};
-            mma_tile_64(Bb, Dv, lj, wave, g, li, false);     // L_j rows 16 wave .. : sum_q R_j[.][q] Dinv[n][q]
-            __syncthreads();
-            acc_tile_to_lds(lj, Bb, wave, g, li);
-            __syncthreads();
-        } else {
-            // L_i itself is the column operand: Bb[16 wave + li][16 b + g + 4 r] = aT[b][r]
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Bb[(16 * wave + li) * LDP + 16 * b + g + 4 * r] = aT[b][r];
-            __syncthreads();
-        }
-        // acc -= L_i L_j^T, k-steps in the order 0, 4, ..., 60 (k0 = 16 b + 4 r): the chain of mma_tile_64
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double a = -aT[b][r];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[nt] = MFMA_F64(a, Bb[(16 * nt + li) * LDP + 16 * b + 4 * r + g], acc[nt]);
-            }
-        if (same && i == k) {
-            // the serial part of the factorisation (this is the only tile of this workgroup)
-            __syncthreads();           // every wave is done reading Bb
-            acc_tile_to_lds(acc, Bb, wave, g, li);
-            __syncthreads();
-            diag_block(Bb, Dv, T16, info + h, k * NB, nullptr, 0, Dinv + ((size_t)h * nblk + k) * NB * NB,
-                       diagL + (size_t)h * Np + (size_t)k * NB);
-            return;
-        }
-        store_tile(row + (size_t)j * LEAN_TILE, acc);
-    }
-}
-
-void launch_lean_fused(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, double* ybuf,
-                       int Np, int k, int nh)
-{
-    const int n = Np / NB - k;                 // block rows k .. nblk-1 still to update (0: only the y block is left)
-    if (n < 0) return;
-    const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_fused),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const dim3 grid = (k == 0) ? dim3(nh, 1, 1)
-                               : dim3(nh, n + 1, n > 0 ? (n + LEAN_CH - 1) / LEAN_CH : 1);
-    hipLaunchKernelGGL(k_lean_fused, grid, dim3(256), lds, s, Lt, Dinv, info, (k == 0) ? nullptr : rhs, diagL, ybuf,
-                       Np, k);
-}
-
-// lp from y in plain storage (k_lean_fused's ybuf) and the diagonal the diagonal blocks left in diagL
-__global__ __launch_bounds__(256) void k_lean_logprob_y(const double* __restrict__ diagL,
-                                                        const double* __restrict__ ybuf,
-                                                        const int* __restrict__ info,
-                                                        double* __restrict__ out, int N, int Np)
-{
-    __shared__ double red[2][256];
-    const int h = blockIdx.x;
-    double sl = 0.0, sq = 0.0;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        sl += log(diagL[(size_t)h * Np + i]);
-        const double gi = ybuf[(size_t)h * Np + i];
-        sq += gi * gi;
-    }
-    red[0][threadIdx.x] = sl;
-    red[1][threadIdx.x] = sq;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + s];
-            red[1][threadIdx.x] += red[1][threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        out[h] = info[h] ? -__builtin_inf() : (-red[0][0] - 0.5 * red[1][0]);
-}
-
-void launch_lean_logprob_y(hipStream_t s, const double* diagL, const double* ybuf, const int* info, double* out, int N,
-                           int Np, int nh)
-{
-    hipLaunchKernelGGL(k_lean_logprob_y, dim3(nh), dim3(256), 0, s, diagL, ybuf, info, out, N, Np);
 }
 
 // lazy = 1: updates are applied two steps at a time (k_lean_step2 at even k >= 2; at odd k only block column k is

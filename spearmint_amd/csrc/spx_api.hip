@@ -136,7 +136,7 @@ void spx_destroy(spx_handle* h)
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
                           &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
-                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ybuf, &h->ps_flags,
+                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ps_flags,
                           &h->alphaS, &h->pt_u, &h->rec_send, &h->rec_recv, &h->rec_out, &h->ei_sum_full};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -176,10 +176,6 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_ps")) {     // log-likelihood path: panel solve pipelined inside the step launch (1, default), separate launch (0)
         h->lean_ps = value < 0 ? -1 : (value != 0);
-        return SPX_OK;
-    }
-    if (!strcmp(name, "lean_fused")) {  // log-likelihood path: one launch per block column (1), step + panel solve (0), by size (-1, default)
-        h->lean_fused = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
     if (!strcmp(name, "streams")) {  // 1 = everything on one stream (default), 2 = alternate EI work items
@@ -343,20 +339,11 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // batch no longer fit the 256 MB Infinity Cache (measured: N=2048 from ~20 draws, N=4096 from 6; -3 ... -16 %),
     // and costs 5-10 % below that.  Same factor either way, bit for bit.
     const int lazy = h->lean_lazy >= 0 ? h->lean_lazy : ((double)nh * Np * Np * 4.0 > 300e6 ? 1 : 0);
-    // One launch per block column (k_lean_fused: every workgroup forms the panel operands it needs itself) unless the
-    // batch is large enough for the lazy two-column updates; same factor, bit for bit.
-    // Measured (scripts/time_lean.py): the fused form wins over step + panel-solve launches where the launch count
-    // dominates (N <= 256: 0.178 vs 0.199 ms of kernels per call) and loses from N = 1024 on (one draw at N = 2048: 30.7 vs
-    // 28.1 us per block column; 8 draws 1.80 vs 1.33 ms) -- its MFMA-heavy workgroups share SIMDs with the wave that runs
-    // the pivots; k_lean_step_ps below beats both from four block columns up.  By default chosen by size (option
-    // lean_fused = -1); 0 / 1 force either form (when lean_ps does not apply).
-    const int want_fused = h->lean_fused >= 0 ? h->lean_fused : (nblk <= 4 ? 1 : 0);
     // Panel solve inside the step launch, pipelined behind the diagonal block's pivots (k_lean_step_ps): option lean_ps
-    // (measured, scripts/dev/lean_option_ab.py: -1 ... -8 % per call from N = 256 up -- 2048: -6.5 % at 4-12 draws, -1 % at
-    // one; 1000: -3 ... -13 %; 4096: -4 ... -5 % -- and no gain over k_lean_fused at two block columns)
-    const int want_ps = h->lean_ps >= 0 ? h->lean_ps : (nblk > 2 ? 1 : 0);
+    // (measured against a launch of its own per panel solve, scripts/dev/lean_option_ab.py: -1 ... -8 % per call from N = 256
+    // up -- 2048: -6.5 % at 4-12 draws, -1 % at one; 1000: -3 ... -13 %; 4096: -4 ... -5 %)
+    const int want_ps = h->lean_ps >= 0 ? h->lean_ps : 1;
     const int ps = (rl && !lazy && want_ps) ? 1 : 0;
-    const int fused = (rl && !ps && !lazy && want_fused) ? 1 : 0;
     if (ps && (rc = h->ps_flags.reserve((size_t)nh * nblk * sizeof(int)))) return rc;   // zeroed by k_lean_rhs_init
     // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
     // so y = L^-1 (vals - mean) is ready when the last column is
@@ -373,13 +360,9 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         }
         h->lean_tiled = rl != 0;
     }
-    h->lean_y = fused != 0;
-    if (fused && (rc = h->ybuf.reserve((size_t)nh * Np * 8))) return rc;
-    for (int k = 0; k < nblk + fused; ++k) {
+    for (int k = 0; k < nblk; ++k) {
         if (ps) {
             TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));
-        } else if (fused) {
-            TIMED(ST_CHOL_DIAG, launch_lean_fused(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), h->ybuf.d(), Np, k, nh));
         } else if (rl) {
             TIMED(ST_CHOL_DIAG, launch_lean_step(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), Np, k, nh, lazy));
             TIMED(ST_CHOL_PANEL, launch_lean_trsm(s, h->Lm.d(), h->Dinv.d(), rhs, Np, k, nh));
@@ -793,9 +776,7 @@ int spx_gp_logprob(spx_handle* h, double* out)
     int rc = do_factor(h, true, true, true);   // K(X,X), Cholesky, forward solve -- no inverse; queued, not yet synchronised
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
-    if (h->lean_tiled && h->lean_y)
-        launch_lean_logprob_y(h->stream, h->diagL.d(), h->ybuf.d(), (const int*)h->info.p, h->lp.d(), (int)h->N, h->Np, h->H);
-    else if (h->lean_tiled)
+    if (h->lean_tiled)
         launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, h->lp.d(), (int)h->N, h->Np, h->H);
     else
         launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);

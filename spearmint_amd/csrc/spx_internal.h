@@ -102,11 +102,8 @@ struct spx_handle {
     DevBuf rhs;                                                     // spx_gp_logprob: [H][64][Np] right-hand-side rows
     DevBuf diagL;                                                   // spx_gp_logprob (tile-major path): diag(L), [H][Np]
     bool lean_tiled = false;                                        // the last lean factorisation used tile-major storage
-    DevBuf ybuf;                                                    // k_lean_fused: y = L^-1 (vals - mean), [H][Np]
-    bool lean_y = false;                                            // the last lean factorisation left y in ybuf
     int lean_ps = -1;                                               // option "lean_ps": 0 / 1 / -1 = default (on)
     DevBuf ps_flags;                                                // k_lean_step_ps: progress of every diagonal block, [H][nblk]
-    int lean_fused = -1;                                            // option "lean_fused": 0 / 1 / -1 = by size
 
     double best_val = 0.0;
     int64_t best_idx = -1;

@@ -349,60 +349,57 @@ def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
                 assert np.array_equal(eng.gp_logprob(), big[lo:hi])
     finally:
         eng.set_option("lean_lazy", -1)
-    # ... nor on whether a block column is one launch (k_lean_fused: every workgroup forms its own panel
-    # operands; the default) or an update launch plus a panel-solve launch (option lean_fused=0)
-    # or an update launch whose first-chunk workgroups also solve their panel tile behind the diagonal block's pivots,
-    # handed the inverse block row by block row inside the launch (k_lean_step_ps, option lean_ps; the default from
-    # four block columns up)
+    # ... nor on whether the panel solve of a block column is a launch of its own (option lean_ps=0) or runs inside the
+    # update launch, its workgroups handed the inverse of the diagonal block row by row behind the pivots
+    # (k_lean_step_ps, the default)
     try:
-        for ps, fused in ((0, 0), (0, 1), (1, 0)):
+        for ps in (0, 1):
             eng.set_option("lean_ps", ps)
-            eng.set_option("lean_fused", fused)
             for lo, hi in ((0, 1), (1, 6), (20, 40)):
                 eng.set_hypers(hypers[lo:hi])
                 assert np.array_equal(eng.gp_logprob(), big[lo:hi])
     finally:
-        eng.set_option("lean_fused", -1)
         eng.set_option("lean_ps", -1)
 
 
-def test_gpu_loglikelihood_fused_columns_at_2048(eng):
-    """The one-launch-per-block-column path at the size it was built for (32 block columns, a chunked block row,
-    the y block of every column, the extra last launch): equal to the two-launch path bit for bit, to LAPACK 1e-11 -- and so is the default from four block columns up, k_lean_step_ps
-    (panel solve handed the inverse of the diagonal block inside the launch)."""
+def test_gpu_loglikelihood_in_launch_panel_solve_at_2048(eng):
+    """The one-launch-per-block-column path (k_lean_step_ps) at the size it was built for -- 32 block columns, chunked block
+    rows, the right-hand-side rows solved like any panel tile: equal to the two-launch path bit for bit, to LAPACK 1e-11; a
+    28-draw batch repeated 25 times (every CU busy with other draws' tiles while panel workgroups wait for their diagonal
+    block) keeps returning the same bits; N not a multiple of 64."""
     comp, cand, vals, hypers = synthetic_problem(2048, 10, 32, 3, 53)
     eng.set_observations(comp, vals)
     try:
         got = {}
-        for name, ps, fused in (("ps", 1, 0), ("fused", 0, 1), ("two", 0, 0)):
+        for name, ps in (("ps", 1), ("two", 0)):
             eng.set_option("lean_ps", ps)
-            eng.set_option("lean_fused", fused)
             eng.set_hypers(hypers)
             got[name] = eng.gp_logprob()
-        assert np.array_equal(got["fused"], got["two"]) and np.array_equal(got["ps"], got["two"])
+        assert np.array_equal(got["ps"], got["two"])
         ref = orc.gp_logprob(comp, vals, hypers[1, 0], hypers[1, 2], hypers[1, 1], hypers[1, 3:])
         assert np.isclose(got["ps"][1], ref, rtol=1e-11)
-        # the in-launch hand-off under load: many draws (every CU busy with other draws' tiles while panel workgroups
-        # wait for their diagonal block), repeated, must keep returning the same bits
         comp3, _, vals3, hyp3 = synthetic_problem(1100, 10, 9, 28, 55)
         eng.set_observations(comp3, vals3)
-        eng.set_option("lean_ps", 0); eng.set_option("lean_fused", 0)
+        eng.set_option("lean_ps", 0)
         eng.set_hypers(hyp3); base = eng.gp_logprob()
         eng.set_option("lean_ps", 1)
         for _ in range(25):
             eng.set_hypers(hyp3)
             assert np.array_equal(eng.gp_logprob(), base)
         comp2, _, vals2, hyp2 = synthetic_problem(1000, 10, 7, 2, 54)      # N not a multiple of 64
-        eng.set_option("lean_ps", 0); eng.set_option("lean_fused", 1)
         eng.set_observations(comp2, vals2)
         eng.set_hypers(hyp2)
         lp = eng.gp_logprob()
+        comp1, _, vals1, hyp1 = synthetic_problem(70, 10, 3, 2, 56)        # two block columns
+        eng.set_observations(comp1, vals1); eng.set_hypers(hyp1)
+        lp1 = eng.gp_logprob()
     finally:
-        eng.set_option("lean_fused", -1)
         eng.set_option("lean_ps", -1)
     for h in range(2):
         ref = orc.gp_logprob(comp2, vals2, hyp2[h, 0], hyp2[h, 2], hyp2[h, 1], hyp2[h, 3:])
         assert np.isclose(lp[h], ref, rtol=1e-11)
+        ref1 = orc.gp_logprob(comp1, vals1, hyp1[h, 0], hyp1[h, 2], hyp1[h, 1], hyp1[h, 3:])
+        assert np.isclose(lp1[h], ref1, rtol=1e-11)
 
 
 # ---- pending experiments ("next" row 2): fantasies on the GPU --------------------------
