@@ -233,7 +233,7 @@ __shared__ long long g_stamp[32];
 template <bool PUB = false>
 __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, int* info_h, int pivot_base,
                                            double* __restrict__ Lkk, size_t ldl, double* __restrict__ Dk,
-                                           double* __restrict__ diag_out = nullptr, int* flag = nullptr)
+                                           double* __restrict__ diag_out = nullptr, int* flag = nullptr, int flag_base = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -295,7 +295,7 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         __syncthreads();
         STAMP(2 + 4 * b);
         // block row b - 1 of the inverse is complete and drained: publish rows 0 .. b - 1
-        if (PUB && b >= 1 && threadIdx.x == 192) __hip_atomic_store(flag, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (PUB && b >= 1 && threadIdx.x == 192) __hip_atomic_store(flag, flag_base + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- phase 2: sub-panel, rows of tile ti = b+1+wave: P <- P Linv16^T ----
         {
             const int ti = b + 1 + wave;
@@ -318,7 +318,14 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         STAMP(4 + 4 * b);
     }
     if (wave == 0 && lane == 0 && bad) {
-        if (*info_h == 0) *info_h = bad;
+        if (PUB) {
+            // several diagonal blocks of a draw can be in flight in one launch (k_lean_flow), on different XCDs: the
+            // lowest failed pivot wins, at device scope (a hand-off timeout, < 0, stays)
+            const int old = atomicCAS(info_h, 0, bad);
+            if (old > bad) atomicMin(info_h, bad);
+        } else if (*info_h == 0) {
+            *info_h = bad;
+        }
     }
     // last row of the inverse: one product with Linv16_3 per block (rows 0-2 went out as they were built)
     if (wave == 3) {         // the last diagonal block of the inverse
@@ -329,7 +336,7 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
     if (wave > 0 && wave < 4) inv_finish<PUB>(t4, XT, T16, Dk, 3, wave - 1, g, li);
     if (PUB) {   // the last block row
         __syncthreads();
-        if (threadIdx.x == 192) __hip_atomic_store(flag, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 192) __hip_atomic_store(flag, flag_base + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     STAMP(17);
     // L_kk (upper part zero), 16 bytes per lane (S is complete since the last barrier); the log-likelihood path
@@ -730,6 +737,228 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
     // rows k .. nblk-1 and the right-hand-side rows; k = 0 has nothing to apply: one chunk (tile (i,0)) per row
     const dim3 grid(nh, n + 1, k == 0 ? 1 : (n + LEAN_CH - 1) / LEAN_CH);
     hipLaunchKernelGGL(k_lean_step_ps, grid, dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, flags, Np, k);
+}
+
+// ---------------------------------------------------------------------------
+// k_lean_flow: the WHOLE factorisation of the log-likelihood path in ONE launch, as a data-flow program.
+//
+// Every dependency of the blocked factorisation -- diagonal block -> panel tile -> update -> next diagonal block --
+// is a hand-off inside the launch (the mechanism k_lean_step_ps proved: write-through stores, drained, a flag;
+// readers past their L1), so no dependency waits for a launch boundary or for unrelated tiles of the same step.
+// A workgroup owns two neighbouring tiles (i, hi-1), (i, hi) of a block row (chunks are aligned to the RIGHT end of
+// the row, so that the tile next to the diagonal and the diagonal tile always share a workgroup) and processes them
+// LEFT-looking, accumulators in registers:
+//   1. history: for k < hi-1 both tiles take step k as soon as L_ik, L_hi-1,k and L_hi,k are published;
+//   2. tile (i, hi-1): the diagonal block (if it is the diagonal tile) or its panel solve, block column by block
+//      column behind the pivots of the diagonal workgroup of that column, then PUBLISHED (tile + flag);
+//   3. tile (i, hi): step hi-1 with the tile just solved, then the diagonal block or the panel solve.
+// Per tile the steps arrive in the order 0, 1, 2, ... through the same MFMA chains as everywhere else: same bits.
+// The dependent chain of a block column is   diagonal block -> (hand-off) -> last quarter of ONE panel solve ->
+// one tile product -> next diagonal block,   all of the last three in the same workgroup.
+// Deadlock freedom does not depend on residency: workgroups are numbered row-major (block row ascending, chunk
+// ascending; draws fastest), every wait is for a tile of a LOWER-numbered workgroup (an earlier chunk of the same
+// row, a row above, the diagonal workgroup of a row above), and workgroups are dispatched in that order -- whoever
+// is waited for has been dispatched.  Waits are one lane polling (relaxed agent-scope loads, s_sleep), bounded.
+// Flags carry the call's generation (no memset per call): Lflag[h][row][col] = gen once tile (row, col) of L is
+// published; Dflag[h][col] = 8 gen + b once block rows 0 .. b-1 of Dinv_col are.
+#define FLOW_SPIN_LIMIT (1 << 20)
+
+// a tile past the non-coherent caches (sc1: device scope), 16 bytes per lane and access like load_tile / store_tile
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#define SPX_SC1 16
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double* tile)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(tile), 0, LEAN_TILE * 8, 0x00020000);
+}
+__device__ __forceinline__ void load_tile_sc1(const double* __restrict__ tile, d4 (&t)[4])
+{
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const d2 lo = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16 + (2 * nt) * 4096, 0, SPX_SC1));
+        const d2 hi = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16 + (2 * nt + 1) * 4096, 0, SPX_SC1));
+        t[nt] = (d4){lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+// the planes of block column nt of a tile (no drain: the caller waits for vmcnt(0) before it raises the flag)
+__device__ __forceinline__ void store_tile_quarter_sc1(double* __restrict__ tile, const d4& v, int nt)
+{
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, (d2){v[0], v[1]}), rs, (int)threadIdx.x * 16 + (2 * nt) * 4096, 0, SPX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, (d2){v[2], v[3]}), rs, (int)threadIdx.x * 16 + (2 * nt + 1) * 4096, 0, SPX_SC1);
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// one lane waits until *f >= want (bounded); everybody leaves together
+__device__ __forceinline__ void flow_wait(const int* f, int want, int* info_h)
+{
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < FLOW_SPIN_LIMIT) {
+            __builtin_amdgcn_s_sleep(8);
+            // somebody else gave up already: do not queue a second timeout behind the first
+            if ((spins & 1023) == 0 && __hip_atomic_load(info_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) break;
+        }
+        if (spins >= FLOW_SPIN_LIMIT) __hip_atomic_store(info_h, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+
+// panel solve of the tile held in R (LDS, [64][LDP]) against Dinv_col, block column by block column behind the
+// diagonal workgroup's progress flag; B is scratch for the published rows
+// (the solved quarters leave for `dst` as they are formed; DIAG: see below, Q = [64][18] scratch)
+template <bool DIAG>
+__device__ __forceinline__ void flow_trsm(const double* R, double* B, const double* __restrict__ Dk, const int* dflag,
+                                          int gen, int* info_h, d4 (&out)[4], double* __restrict__ dst, double* Q, d4 (&a1)[4],
+                                          int wave, int g, int li)
+{
+    for (int b = 0; b < 4; ++b) {
+        flow_wait(dflag, 8 * gen + b + 1, info_h);
+        double dv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m <= b) {
+                const int e = threadIdx.x + 256 * m;
+                dv[m] = __hip_atomic_load(Dk + (16 * b + e / (16 * (b + 1))) * NB + e % (16 * (b + 1)), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m <= b) {
+                const int e = threadIdx.x + 256 * m;
+                B[(16 * b + e / (16 * (b + 1))) * LDP + e % (16 * (b + 1))] = dv[m];
+            }
+        __syncthreads();
+        out[b] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < 16 * (b + 1); k0 += 4)
+            out[b] = MFMA_F64(R[(16 * wave + li) * LDP + k0 + g], B[(16 * b + li) * LDP + k0 + g], out[b]);
+        store_tile_quarter_sc1(dst, out[b], b);      // on its way while the next quarter waits
+        if (DIAG) {
+            // the owner of the next diagonal block: step lo of tile (i,i), a1 -= L_i,lo L_i,lo^T, follows the solve
+            // quarter by quarter (k ascending per accumulator, like mma_tile_64: same bits) -- behind the last pivot
+            // of the block above there is a quarter of a solve and a quarter of a product, not a whole one
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Q[(16 * wave + g + 4 * r) * 18 + li] = out[b][r];
+            __syncthreads();
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4) {
+                const double a = -Q[(16 * wave + li) * 18 + k0 + g];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) a1[nt] = MFMA_F64(a, Q[(16 * nt + li) * 18 + k0 + g], a1[nt]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, double* __restrict__ Dinv,
+                                                   int* __restrict__ info, double* __restrict__ rhs,
+                                                   double* __restrict__ diagL, int* __restrict__ lflags,
+                                                   int* __restrict__ dflags, int Np, int gen)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;              // [64][LDP]
+    double* B = smem + NB * LDP;   // [64][LDP]
+    double* T16 = B + NB * LDP;    // [4][16][18]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x;
+    const int nblk = Np / NB;
+    // blockIdx.y -> (block row i, chunk c): rows 0 .. nblk-1 have (i + 2) / 2 chunks, the right-hand-side rows
+    // (i = nblk, tiles 0 .. nblk-1) (nblk + 1) / 2
+    int i = 0, c = (int)blockIdx.y;
+    for (;;) {
+        const int nc = (i < nblk) ? (i + 2) / 2 : (nblk + 1) / 2;
+        if (c < nc) break;
+        c -= nc;
+        ++i;
+    }
+    const bool is_rhs = (i == nblk);
+    const int last = is_rhs ? nblk - 1 : i;                       // last tile column of this row
+    const int ncr = (last + 2) / 2;
+    const int hi = last - 2 * (ncr - 1 - c);                     // this chunk: columns hi - 1 (if >= 0) and hi
+    const int lo = hi - 1;
+    const bool two = lo >= 0;
+    double* Lh = Lt + (size_t)h * Np * Np;
+    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
+    int* info_h = info + h;
+    const int* lf = lflags + (size_t)h * (nblk + 1) * nblk;     // [row][col]
+    int* lf_row = lflags + ((size_t)h * (nblk + 1) + i) * nblk;
+    int* df = dflags + (size_t)h * nblk;
+    double* Dh = Dinv + (size_t)h * nblk * NB * NB;
+
+    d4 a0[4], a1[4], st[4];
+    if (two) load_tile(row + (size_t)lo * LEAN_TILE, a0);
+    load_tile(row + (size_t)hi * LEAN_TILE, a1);
+    // ---- 1. history: steps k < first column of the chunk ----
+    const int first = two ? lo : hi;
+    for (int k = 0; k < first; ++k) {
+        flow_wait(lf_row + k, gen, info_h);                                  // L_ik (an earlier chunk of this row)
+        load_tile_sc1(row + (size_t)k * LEAN_TILE, st);
+        acc_tile_to_lds(st, A, wave, g, li);
+        if (two) {
+            flow_wait(lf + (size_t)lo * nblk + k, gen, info_h);              // L_lo,k (a row above); the barrier also covers A
+            load_tile_sc1(Lh + ((size_t)lo * nblk + k) * LEAN_TILE, st);
+            acc_tile_to_lds(st, B, wave, g, li);
+            __syncthreads();
+            mma_tile_64(A, B, a0, wave, g, li, true);
+            __syncthreads();
+        }
+        if (!is_rhs && hi == i) {                                            // the diagonal tile: L_hi,k is L_ik
+            if (!two) __syncthreads();
+            mma_tile_64(A, A, a1, wave, g, li, true);
+        } else {
+            flow_wait(lf + (size_t)hi * nblk + k, gen, info_h);
+            load_tile_sc1(Lh + ((size_t)hi * nblk + k) * LEAN_TILE, st);
+            acc_tile_to_lds(st, B, wave, g, li);
+            __syncthreads();
+            mma_tile_64(A, B, a1, wave, g, li, true);
+        }
+        __syncthreads();                                                     // A and B are rewritten next step
+    }
+    // ---- 2. tile (i, lo): always a panel tile (lo < hi <= i) ----
+    const bool diag = !is_rhs && hi == i;
+    if (two) {
+        acc_tile_to_lds(a0, A, wave, g, li);
+        if (diag) {
+            flow_trsm<true>(A, B, Dh + (size_t)lo * NB * NB, df + lo, gen, info_h, st, row + (size_t)lo * LEAN_TILE, T16, a1, wave, g, li);
+        } else {
+            flow_trsm<false>(A, B, Dh + (size_t)lo * NB * NB, df + lo, gen, info_h, st, row + (size_t)lo * LEAN_TILE, T16, a1, wave, g, li);
+            // step lo of tile (i, hi): with the tile just solved as the row operand
+            __syncthreads();                                                 // every wave is done with R
+            acc_tile_to_lds(st, A, wave, g, li);
+            flow_wait(lf + (size_t)hi * nblk + lo, gen, info_h);             // L_hi,lo (row hi's own diagonal chunk)
+            d4 tb[4];
+            load_tile_sc1(Lh + ((size_t)hi * nblk + lo) * LEAN_TILE, tb);
+            acc_tile_to_lds(tb, B, wave, g, li);
+            __syncthreads();
+            mma_tile_64(A, B, a1, wave, g, li, true);
+        }
+        drain_stores();                                                      // L_i,lo is out (written through) ...
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(lf_row + lo, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and says so
+    }
+    // ---- 3. tile (i, hi) ----
+    acc_tile_to_lds(a1, A, wave, g, li);
+    __syncthreads();
+    if (diag) {
+        diag_block<true>(A, B, T16, info_h, i * NB, nullptr, 0, Dh + (size_t)i * NB * NB, diagL + (size_t)h * Np + (size_t)i * NB,
+                         df + i, 8 * gen);
+    } else {
+        flow_trsm<false>(A, B, Dh + (size_t)hi * NB * NB, df + hi, gen, info_h, st, row + (size_t)hi * LEAN_TILE, T16, a1, wave, g, li);
+        drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(lf_row + hi, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
+                      int* dflags, int Np, int nh, int gen)
+{
+    const int nblk = Np / NB;
+    int ny = (nblk + 1) / 2;                                   // the right-hand-side rows
+    for (int i = 0; i < nblk; ++i) ny += (i + 2) / 2;
+    const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_lean_flow, dim3(nh, ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, Np, gen);
 }
 
 // k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile right of block column k (which needs

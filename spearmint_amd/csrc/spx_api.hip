@@ -136,7 +136,7 @@ void spx_destroy(spx_handle* h)
                           &h->fantT, &h->gammaS, &h->bests, &h->part_bgS[0], &h->part_bgS[1],
                           &h->pt_x, &h->pt_k, &h->pt_dk, &h->pt_t, &h->pt_z, &h->pt_out, &h->pt_kt, &h->pt_dkt,
                           &h->ei_draw, &h->ei_mean, &h->mom_m, &h->mom_v, &h->mom_t, &h->am_val, &h->am_idx,
-                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ps_flags,
+                          &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ps_flags, &h->flow_flags,
                           &h->alphaS, &h->pt_u, &h->rec_send, &h->rec_recv, &h->rec_out, &h->ei_sum_full};
         for (DevBuf* b : bufs) b->release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -172,6 +172,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_lazy")) {   // log-likelihood path: trailing updates two steps at a time (1), one (0), by size (-1, default)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "lean_flow")) {   // log-likelihood path: the whole factorisation as ONE data-flow launch (1), per-column launches (0)
+        h->lean_flow = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
     if (!strcmp(name, "lean_ps")) {     // log-likelihood path: panel solve pipelined inside the step launch (1, default), separate launch (0)
@@ -345,6 +349,21 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     const int want_ps = h->lean_ps >= 0 ? h->lean_ps : 1;
     const int ps = (rl && !lazy && want_ps) ? 1 : 0;
     if (ps && (rc = h->ps_flags.reserve((size_t)nh * nblk * sizeof(int)))) return rc;   // zeroed by k_lean_rhs_init
+    // The whole factorisation as one data-flow launch (k_lean_flow): option lean_flow
+    const int flow = (rl && h->lean_flow > 0) ? 1 : 0;
+    int* lflags = nullptr; int* dflags = nullptr;
+    if (flow) {
+        const size_t nfl = (size_t)nh * (nblk + 1) * nblk + (size_t)nh * nblk;
+        if (nfl > h->flow_flags_n || h->flow_gen >= (1 << 27)) {
+            if ((rc = h->flow_flags.reserve(nfl * sizeof(int)))) return rc;
+            HIPCHK(hipMemsetAsync(h->flow_flags.p, 0, h->flow_flags.cap, h->stream));
+            h->flow_flags_n = h->flow_flags.cap / sizeof(int);
+            h->flow_gen = 0;
+        }
+        h->flow_gen += 1;
+        lflags = (int*)h->flow_flags.p;
+        dflags = lflags + (size_t)nh * (nblk + 1) * nblk;
+    }
     // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
     // so y = L^-1 (vals - mean) is ready when the last column is
     double* rhs = nullptr;
@@ -360,7 +379,9 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         }
         h->lean_tiled = rl != 0;
     }
-    for (int k = 0; k < nblk; ++k) {
+    if (flow)
+        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), lflags, dflags, Np, nh, h->flow_gen));
+    for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {
             TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));
         } else if (rl) {
