@@ -755,12 +755,15 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 // Per tile the steps arrive in the order 0, 1, 2, ... through the same MFMA chains as everywhere else: same bits.
 // The dependent chain of a block column is   diagonal block -> (hand-off) -> last quarter of ONE panel solve ->
 // one tile product -> next diagonal block,   all of the last three in the same workgroup.
-// Deadlock freedom does not depend on residency: workgroups are numbered row-major (block row ascending, chunk
-// ascending; draws fastest), every wait is for a tile of a LOWER-numbered workgroup (an earlier chunk of the same
-// row, a row above, the diagonal workgroup of a row above), and workgroups are dispatched in that order -- whoever
-// is waited for has been dispatched.  Waits are one lane polling (relaxed agent-scope loads, s_sleep), bounded.
-// Flags carry the call's generation (no memset per call): Lflag[h][row][col] = gen once tile (row, col) of L is
-// published; Dflag[h][col] = 8 gen + b once block rows 0 .. b-1 of Dinv_col are.
+// Deadlock freedom does not depend on residency: work items are numbered row-major (block row ascending, chunk
+// ascending; draws fastest), every wait is for a tile of a LOWER-numbered item (an earlier chunk of the same
+// row, a row above, the diagonal item of a row above), and a workgroup takes its item from a ticket counter when it
+// starts -- whoever is waited for is running or done.  Waits are one lane polling (relaxed agent-scope loads,
+// s_sleep), bounded: a timeout is an error (info < 0), never a hang.
+// Flags carry the call's generation (no memset per call): Lflag[h][row][col] = 8 gen once tile (row, col) of L is
+// published; Dflag[h][col] = 8 gen + b once block rows 0 .. b-1 of Dinv_col are.  One scale for both kinds: the batch
+// size and the matrix size change between calls and with them which word is which flag -- whatever an earlier call
+// left anywhere is below 8 gen.
 #define FLOW_SPIN_LIMIT (1 << 20)
 
 // a tile past the non-coherent caches (sc1: device scope), 16 bytes per lane and access like load_tile / store_tile
@@ -852,7 +855,8 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
 __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, double* __restrict__ Dinv,
                                                    int* __restrict__ info, double* __restrict__ rhs,
                                                    double* __restrict__ diagL, int* __restrict__ lflags,
-                                                   int* __restrict__ dflags, int Np, int gen)
+                                                   int* __restrict__ dflags, unsigned* __restrict__ tickets,
+                                                   unsigned ticket_base, int Np, int nh, int gen)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;              // [64][LDP]
@@ -860,11 +864,17 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     double* T16 = B + NB * LDP;    // [4][16][18]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.x;
+    // Work is handed out by TICKET, not by blockIdx: a workgroup that holds ticket t is running, and every ticket
+    // below t was taken by a workgroup that is running or done -- the order the deadlock argument above needs, by
+    // construction rather than by the dispatcher's habits.  Draws fastest: the diagonal workgroups of all draws first.
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(tickets, 1u) - ticket_base;
+    __syncthreads();
+    const int h = (int)(s_ticket % (unsigned)nh);
     const int nblk = Np / NB;
-    // blockIdx.y -> (block row i, chunk c): rows 0 .. nblk-1 have (i + 2) / 2 chunks, the right-hand-side rows
+    // ticket / nh -> (block row i, chunk c): rows 0 .. nblk-1 have (i + 2) / 2 chunks, the right-hand-side rows
     // (i = nblk, tiles 0 .. nblk-1) (nblk + 1) / 2
-    int i = 0, c = (int)blockIdx.y;
+    int i = 0, c = (int)(s_ticket / (unsigned)nh);
     for (;;) {
         const int nc = (i < nblk) ? (i + 2) / 2 : (nblk + 1) / 2;
         if (c < nc) break;
@@ -891,11 +901,11 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     // ---- 1. history: steps k < first column of the chunk ----
     const int first = two ? lo : hi;
     for (int k = 0; k < first; ++k) {
-        flow_wait(lf_row + k, gen, info_h);                                  // L_ik (an earlier chunk of this row)
+        flow_wait(lf_row + k, 8 * gen, info_h);                                  // L_ik (an earlier chunk of this row)
         load_tile_sc1(row + (size_t)k * LEAN_TILE, st);
         acc_tile_to_lds(st, A, wave, g, li);
         if (two) {
-            flow_wait(lf + (size_t)lo * nblk + k, gen, info_h);              // L_lo,k (a row above); the barrier also covers A
+            flow_wait(lf + (size_t)lo * nblk + k, 8 * gen, info_h);              // L_lo,k (a row above); the barrier also covers A
             load_tile_sc1(Lh + ((size_t)lo * nblk + k) * LEAN_TILE, st);
             acc_tile_to_lds(st, B, wave, g, li);
             __syncthreads();
@@ -906,7 +916,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
             if (!two) __syncthreads();
             mma_tile_64(A, A, a1, wave, g, li, true);
         } else {
-            flow_wait(lf + (size_t)hi * nblk + k, gen, info_h);
+            flow_wait(lf + (size_t)hi * nblk + k, 8 * gen, info_h);
             load_tile_sc1(Lh + ((size_t)hi * nblk + k) * LEAN_TILE, st);
             acc_tile_to_lds(st, B, wave, g, li);
             __syncthreads();
@@ -925,7 +935,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
             // step lo of tile (i, hi): with the tile just solved as the row operand
             __syncthreads();                                                 // every wave is done with R
             acc_tile_to_lds(st, A, wave, g, li);
-            flow_wait(lf + (size_t)hi * nblk + lo, gen, info_h);             // L_hi,lo (row hi's own diagonal chunk)
+            flow_wait(lf + (size_t)hi * nblk + lo, 8 * gen, info_h);             // L_hi,lo (row hi's own diagonal chunk)
             d4 tb[4];
             load_tile_sc1(Lh + ((size_t)hi * nblk + lo) * LEAN_TILE, tb);
             acc_tile_to_lds(tb, B, wave, g, li);
@@ -934,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
         }
         drain_stores();                                                      // L_i,lo is out (written through) ...
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(lf_row + lo, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and says so
+        if (threadIdx.x == 0) __hip_atomic_store(lf_row + lo, 8 * gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and says so
     }
     // ---- 3. tile (i, hi) ----
     acc_tile_to_lds(a1, A, wave, g, li);
@@ -946,19 +956,21 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
         flow_trsm<false>(A, B, Dh + (size_t)hi * NB * NB, df + hi, gen, info_h, st, row + (size_t)hi * LEAN_TILE, T16, a1, wave, g, li);
         drain_stores();
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(lf_row + hi, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(lf_row + hi, 8 * gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
-                      int* dflags, int Np, int nh, int gen)
+                      int* dflags, unsigned* tickets, unsigned* ticket_base, int Np, int nh, int gen)
 {
     const int nblk = Np / NB;
     int ny = (nblk + 1) / 2;                                   // the right-hand-side rows
     for (int i = 0; i < nblk; ++i) ny += (i + 2) / 2;
     const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_lean_flow, dim3(nh, ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, Np, gen);
+    hipLaunchKernelGGL(k_lean_flow, dim3(nh * ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, tickets,
+                       *ticket_base, Np, nh, gen);
+    *ticket_base += (unsigned)(nh * ny);                       // every workgroup takes exactly one ticket
 }
 
 // k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile right of block column k (which needs

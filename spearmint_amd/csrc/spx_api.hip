@@ -174,7 +174,7 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
-    if (!strcmp(name, "lean_flow")) {   // log-likelihood path: the whole factorisation as ONE data-flow launch (1), per-column launches (0)
+    if (!strcmp(name, "lean_flow")) {   // log-likelihood path: the whole factorisation as ONE data-flow launch (1, default), one launch per block column (0)
         h->lean_flow = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
@@ -347,23 +347,28 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // (measured against a launch of its own per panel solve, scripts/dev/lean_option_ab.py: -1 ... -8 % per call from N = 256
     // up -- 2048: -6.5 % at 4-12 draws, -1 % at one; 1000: -3 ... -13 %; 4096: -4 ... -5 %)
     const int want_ps = h->lean_ps >= 0 ? h->lean_ps : 1;
-    const int ps = (rl && !lazy && want_ps) ? 1 : 0;
+    const int ps = (rl && !lazy && want_ps && h->lean_flow == 0) ? 1 : 0;   // (only without lean_flow, below)
     if (ps && (rc = h->ps_flags.reserve((size_t)nh * nblk * sizeof(int)))) return rc;   // zeroed by k_lean_rhs_init
-    // The whole factorisation as one data-flow launch (k_lean_flow): option lean_flow
-    const int flow = (rl && h->lean_flow > 0) ? 1 : 0;
-    int* lflags = nullptr; int* dflags = nullptr;
+    // The whole factorisation as ONE data-flow launch (k_lean_flow; option lean_flow, default on): against one launch per
+    // block column -20 % per call at N = 2048 (1-4 draws; -8 ... -13 % at 8-32), -10 % at N = 1000, -5 % at N = 256,
+    // level below (scripts/dev/flow_ab.py); the same factor bit for bit
+    const int flow = (rl && h->lean_flow != 0) ? 1 : 0;
+    int* lflags = nullptr; int* dflags = nullptr; unsigned* tickets = nullptr;
     if (flow) {
-        const size_t nfl = (size_t)nh * (nblk + 1) * nblk + (size_t)nh * nblk;
+        const size_t nfl = (size_t)nh * (nblk + 1) * nblk + (size_t)nh * nblk + 1;
         if (nfl > h->flow_flags_n || h->flow_gen >= (1 << 27)) {
             if ((rc = h->flow_flags.reserve(nfl * sizeof(int)))) return rc;
             HIPCHK(hipMemsetAsync(h->flow_flags.p, 0, h->flow_flags.cap, h->stream));
             h->flow_flags_n = h->flow_flags.cap / sizeof(int);
             h->flow_gen = 0;
+            h->flow_ticket_base = 0;
         }
         h->flow_gen += 1;
-        lflags = (int*)h->flow_flags.p;
+        tickets = (unsigned*)h->flow_flags.p;          // first: its place does not move with the batch size
+        lflags = (int*)h->flow_flags.p + 1;
         dflags = lflags + (size_t)nh * (nblk + 1) * nblk;
     }
+    h->flow_used = flow != 0;
     // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
     // so y = L^-1 (vals - mean) is ready when the last column is
     double* rhs = nullptr;
@@ -380,7 +385,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         h->lean_tiled = rl != 0;
     }
     if (flow)
-        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), lflags, dflags, Np, nh, h->flow_gen));
+        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), lflags, dflags, tickets, &h->flow_ticket_base, Np, nh, h->flow_gen));
     for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {
             TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));
@@ -421,8 +426,10 @@ static int finish_factor(spx_handle* h, const std::vector<int>& info, bool toler
     }
     h->not_pd_draw = h->not_pd_pivot = -1;
     for (int i = 0; i < nh; ++i)
-        if (info[i] < 0)   // k_lean_step_ps: a panel workgroup gave up waiting for the diagonal block (bounded spin)
+        if (info[i] < 0) { // k_lean_flow / k_lean_step_ps: a workgroup gave up waiting for a tile or a diagonal block (bounded spin)
+            h->handoff_timeout = true;
             return fail(SPX_ERR_HIP, "log-likelihood factorisation: in-launch hand-off timed out (draw %d)", i);
+        }
     for (int i = 0; i < nh; ++i)
         if (info[i]) { h->not_pd_draw = i; h->not_pd_pivot = info[i] - 1; break; }
     h->factored = !lean;
@@ -790,10 +797,27 @@ int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, doubl
     return SPX_OK;
 }
 
+static int gp_logprob_once(spx_handle* h, double* out);
+
 int spx_gp_logprob(spx_handle* h, double* out)
 {
     if (!h || !out) return fail(SPX_ERR_ARG, "spx_gp_logprob: null");
     if (h->multi) return spx_multi_gp_logprob(h->multi, out);
+    h->handoff_timeout = false;
+    int rc = gp_logprob_once(h, out);
+    if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {
+        // never seen on a healthy device; if the one-launch data flow ever stalls (its spins are bounded), the call is
+        // repeated with one launch per block column -- same kernels' arithmetic, same bits -- and the handle stays there
+        fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
+        h->lean_flow = 0;
+        h->handoff_timeout = false;
+        rc = gp_logprob_once(h, out);
+    }
+    return rc;
+}
+
+static int gp_logprob_once(spx_handle* h, double* out)
+{
     int rc = do_factor(h, true, true, true);   // K(X,X), Cholesky, forward solve -- no inverse; queued, not yet synchronised
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;

@@ -105,9 +105,12 @@ struct spx_handle {
     int lean_ps = -1;                                               // option "lean_ps": 0 / 1 / -1 = default (on)
     DevBuf ps_flags;                                                // k_lean_step_ps: progress of every diagonal block, [H][nblk]
     int lean_flow = -1;                                             // option "lean_flow": whole factorisation in one launch (k_lean_flow)
-    DevBuf flow_flags;                                              // k_lean_flow: [H][nblk + 1][nblk] tile flags + [H][nblk] diagonal progress
+    DevBuf flow_flags;                                              // k_lean_flow: [H][nblk + 1][nblk] tile flags + [H][nblk] diagonal progress + the ticket counter
     size_t flow_flags_n = 0;                                        // ints the flags were zeroed for
     int flow_gen = 0;                                               // generation of the last call (flags are compared, not cleared)
+    bool handoff_timeout = false;                                   // finish_factor saw info < 0
+    bool flow_used = false;                                         // the last factorisation ran k_lean_flow
+    unsigned flow_ticket_base = 0;                                  // tickets handed out by all earlier calls (the counter is never reset)
 
     double best_val = 0.0;
     int64_t best_idx = -1;

@@ -339,65 +339,91 @@ def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
     for h in (0, 19, 39):
         ref = orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:])
         assert np.isclose(big[h], ref, rtol=1e-11)
-    # ... nor on whether the trailing updates are applied one or two block columns at a time (option lean_lazy;
-    # by default chosen from the batch's size)
+    # ... nor on whether the factorisation is ONE data-flow launch (k_lean_flow, the default) or one launch per block column
     try:
+        for flow in (1, 0):
+            eng.set_option("lean_flow", flow)
+            for lo, hi in ((0, 1), (1, 6), (6, 38), (20, 40)):
+                eng.set_hypers(hypers[lo:hi])
+                assert np.array_equal(eng.gp_logprob(), big[lo:hi])
+        # (what follows: the forms with one launch or two per block column)
+        # ... nor on whether the trailing updates are applied one or two block columns at a time (option lean_lazy;
+        # by default chosen from the batch's size)
         for lazy in (0, 1):
             eng.set_option("lean_lazy", lazy)
             for lo, hi in ((0, 1), (1, 6), (20, 40)):
                 eng.set_hypers(hypers[lo:hi])
                 assert np.array_equal(eng.gp_logprob(), big[lo:hi])
-    finally:
         eng.set_option("lean_lazy", -1)
-    # ... nor on whether the panel solve of a block column is a launch of its own (option lean_ps=0) or runs inside the
-    # update launch, its workgroups handed the inverse of the diagonal block row by row behind the pivots
-    # (k_lean_step_ps, the default)
-    try:
+        # ... nor on whether the panel solve of a block column is a launch of its own (option lean_ps=0) or runs inside the
+        # update launch, its workgroups handed the inverse of the diagonal block row by row behind the pivots
+        # (k_lean_step_ps)
         for ps in (0, 1):
             eng.set_option("lean_ps", ps)
             for lo, hi in ((0, 1), (1, 6), (20, 40)):
                 eng.set_hypers(hypers[lo:hi])
                 assert np.array_equal(eng.gp_logprob(), big[lo:hi])
     finally:
+        eng.set_option("lean_lazy", -1)
         eng.set_option("lean_ps", -1)
+        eng.set_option("lean_flow", -1)
+
+
+def _lean_form(eng, form):
+    """The three forms of the log-likelihood factorisation: "flow" one data-flow launch (default), "ps" one launch per
+    block column with the panel solve inside, "two" two launches per block column."""
+    eng.set_option("lean_flow", {"flow": 1, "ps": 0, "two": 0, None: -1}[form])
+    eng.set_option("lean_ps", {"flow": -1, "ps": 1, "two": 0, None: -1}[form])
 
 
 def test_gpu_loglikelihood_in_launch_panel_solve_at_2048(eng):
-    """The one-launch-per-block-column path (k_lean_step_ps) at the size it was built for -- 32 block columns, chunked block
-    rows, the right-hand-side rows solved like any panel tile: equal to the two-launch path bit for bit, to LAPACK 1e-11; a
-    28-draw batch repeated 25 times (every CU busy with other draws' tiles while panel workgroups wait for their diagonal
-    block) keeps returning the same bits; N not a multiple of 64."""
+    """The in-launch hand-off paths -- k_lean_flow (the whole factorisation one launch: tiles and diagonal inverses handed
+    from workgroup to workgroup) and k_lean_step_ps (one launch per block column, the diagonal inverse handed to the panel
+    workgroups) -- at the size they were built for, 32 block columns, the right-hand-side rows solved like any panel
+    tile: equal to the two-launch path bit for bit, to LAPACK 1e-11; a 28-draw batch repeated 25 times (far more
+    workgroups than the chip holds, every CU busy with other draws' tiles while workgroups wait) keeps returning the same
+    bits; N not a multiple of 64; one and two block columns."""
     comp, cand, vals, hypers = synthetic_problem(2048, 10, 32, 3, 53)
     eng.set_observations(comp, vals)
     try:
         got = {}
-        for name, ps in (("ps", 1), ("two", 0)):
-            eng.set_option("lean_ps", ps)
+        for name in ("flow", "ps", "two"):
+            _lean_form(eng, name)
             eng.set_hypers(hypers)
             got[name] = eng.gp_logprob()
         assert np.array_equal(got["ps"], got["two"])
+        assert np.array_equal(got["flow"], got["two"])
         ref = orc.gp_logprob(comp, vals, hypers[1, 0], hypers[1, 2], hypers[1, 1], hypers[1, 3:])
-        assert np.isclose(got["ps"][1], ref, rtol=1e-11)
+        assert np.isclose(got["flow"][1], ref, rtol=1e-11)
         comp3, _, vals3, hyp3 = synthetic_problem(1100, 10, 9, 28, 55)
         eng.set_observations(comp3, vals3)
-        eng.set_option("lean_ps", 0)
+        _lean_form(eng, "two")
         eng.set_hypers(hyp3); base = eng.gp_logprob()
-        eng.set_option("lean_ps", 1)
-        for _ in range(25):
-            eng.set_hypers(hyp3)
-            assert np.array_equal(eng.gp_logprob(), base)
-        comp2, _, vals2, hyp2 = synthetic_problem(1000, 10, 7, 2, 54)      # N not a multiple of 64
-        eng.set_observations(comp2, vals2)
-        eng.set_hypers(hyp2)
-        lp = eng.gp_logprob()
-        comp1, _, vals1, hyp1 = synthetic_problem(70, 10, 3, 2, 56)        # two block columns
-        eng.set_observations(comp1, vals1); eng.set_hypers(hyp1)
-        lp1 = eng.gp_logprob()
+        for name in ("ps", "flow"):
+            _lean_form(eng, name)
+            for _ in range(25):
+                eng.set_hypers(hyp3)
+                assert np.array_equal(eng.gp_logprob(), base), name
+        lp = {}
+        for name in ("flow", "ps"):
+            _lean_form(eng, name)
+            comp2, _, vals2, hyp2 = synthetic_problem(1000, 10, 7, 2, 54)      # N not a multiple of 64
+            eng.set_observations(comp2, vals2)
+            eng.set_hypers(hyp2)
+            lp[name] = eng.gp_logprob()
+            for n1, seed in ((70, 56), (40, 57)):                              # two block columns; one
+                comp1, _, vals1, hyp1 = synthetic_problem(n1, 10, 3, 2, seed)
+                eng.set_observations(comp1, vals1); eng.set_hypers(hyp1)
+                lp1 = eng.gp_logprob()
+                for h in range(2):
+                    ref = orc.gp_logprob(comp1, vals1, hyp1[h, 0], hyp1[h, 2], hyp1[h, 1], hyp1[h, 3:])
+                    assert np.isclose(lp1[h], ref, rtol=1e-11)
     finally:
-        eng.set_option("lean_ps", -1)
+        _lean_form(eng, None)
+    assert np.array_equal(lp["flow"], lp["ps"])
     for h in range(2):
         ref = orc.gp_logprob(comp2, vals2, hyp2[h, 0], hyp2[h, 2], hyp2[h, 1], hyp2[h, 3:])
-        assert np.isclose(lp[h], ref, rtol=1e-11)
+        assert np.isclose(lp["flow"][h], ref, rtol=1e-11)
         ref1 = orc.gp_logprob(comp1, vals1, hyp1[h, 0], hyp1[h, 2], hyp1[h, 1], hyp1[h, 3:])
         assert np.isclose(lp1[h], ref1, rtol=1e-11)
 
@@ -590,8 +616,8 @@ def test_opt_chooser_rescore_grid_does_not_change_the_proposal(tmp_path, npend, 
 
 
 def test_in_launch_handoff_under_concurrent_load(eng):
-    """k_lean_step_ps hands the inverse of every diagonal block to the panel workgroups inside the launch (write-through
-    stores, drained, then a flag; readers past their L1).  A stale read would show as different bits -- looked for here
+    """k_lean_flow and k_lean_step_ps hand tiles of L and the inverse of every diagonal block from workgroup to workgroup
+    inside a launch (write-through stores, drained, then a flag; readers past their L1).  A stale read would show as different bits -- looked for here
     under UNEVEN load: a second engine keeps the GPU busy with EI grids from another host thread while random sizes and
     batch sizes go through the hand-off repeatedly; the two-launch path is the reference, bit for bit."""
     import threading
@@ -615,14 +641,15 @@ def test_in_launch_handoff_under_concurrent_load(eng):
             if rs.rand() < 0.25:
                 hyp[rs.randint(H), 2] = -1.0             # a non-PD draw: its workgroups must not hold the others up
             eng.set_observations(comp, vals)
-            eng.set_option("lean_ps", 0)
+            _lean_form(eng, "two")
             eng.set_hypers(hyp)
             ref = eng.gp_logprob()
-            eng.set_option("lean_ps", 1)
-            for rep in range(5):
-                eng.set_hypers(hyp)
-                assert np.array_equal(eng.gp_logprob(), ref), (N, H, rep)
+            for name in ("flow", "ps"):
+                _lean_form(eng, name)
+                for rep in range(4):
+                    eng.set_hypers(hyp)
+                    assert np.array_equal(eng.gp_logprob(), ref), (name, N, H, rep)
     finally:
         stop.append(1)
         th.join()
-        eng.set_option("lean_ps", -1)
+        _lean_form(eng, None)
