@@ -755,16 +755,17 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 // Per tile the steps arrive in the order 0, 1, 2, ... through the same MFMA chains as everywhere else: same bits.
 // The dependent chain of a block column is   diagonal block -> (hand-off) -> last quarter of ONE panel solve ->
 // one tile product -> next diagonal block,   all of the last three in the same workgroup.
-// Deadlock freedom does not depend on residency: work items are numbered row-major (block row ascending, chunk
-// ascending; draws fastest), every wait is for a tile of a LOWER-numbered item (an earlier chunk of the same
-// row, a row above, the diagonal item of a row above), and a workgroup takes its item from a ticket counter when it
-// starts -- whoever is waited for is running or done.  Waits are one lane polling (relaxed agent-scope loads,
+// Deadlock freedom does not depend on residency: work items are numbered column-major (last column ascending, block
+// row ascending; draws fastest), every wait is for a tile of a LOWER-numbered item (columns to the left in the same
+// row or in a row above; the diagonal item of the same column, a row above), and a workgroup takes its item from a
+// ticket counter when it starts -- whoever is waited for is running or done.  Waits are one lane polling (relaxed agent-scope loads,
 // s_sleep), bounded: a timeout is an error (info < 0), never a hang.
 // Flags carry the call's generation (no memset per call): Lflag[h][row][col] = 8 gen once tile (row, col) of L is
 // published; Dflag[h][col] = 8 gen + b once block rows 0 .. b-1 of Dinv_col are.  One scale for both kinds: the batch
 // size and the matrix size change between calls and with them which word is which flag -- whatever an earlier call
 // left anywhere is below 8 gen.
 #define FLOW_SPIN_LIMIT (1 << 20)
+#define FLOW_BATCH 8        // history steps looked at per poll (3 flags each: 24 lanes)
 
 // a tile past the non-coherent caches (sc1: device scope), 16 bytes per lane and access like load_tile / store_tile
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -782,6 +783,22 @@ __device__ __forceinline__ void load_tile_sc1(const double* __restrict__ tile, d
         const d2 hi = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16 + (2 * nt + 1) * 4096, 0, SPX_SC1));
         t[nt] = (d4){lo[0], lo[1], hi[0], hi[1]};
     }
+}
+// the same into eight 16-byte pieces (plane p = values 2p, 2p + 1 of the accumulator order): a tile that is only on its
+// way to LDS is not assembled into 32-byte accumulator registers (the register allocator pays for that with copies)
+__device__ __forceinline__ void load_tile_sc1_p(const double* __restrict__ tile, d2 (&t)[8])
+{
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile);
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+        t[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16 + p * 4096, 0, SPX_SC1));
+}
+__device__ __forceinline__ void planes_to_lds(const d2 (&t)[8], double* lds, int wave, int g, int li)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[(16 * wave + g + 4 * r) * LDP + 16 * nt + li] = t[2 * nt + (r >> 1)][r & 1];
 }
 // the planes of block column nt of a tile (no drain: the caller waits for vmcnt(0) before it raises the flag)
 __device__ __forceinline__ void store_tile_quarter_sc1(double* __restrict__ tile, const d4& v, int nt)
@@ -806,24 +823,56 @@ __device__ __forceinline__ void flow_wait(const int* f, int want, int* info_h)
     __syncthreads();
 }
 
+// one lane waits until *f >= want (bounded) and tells everybody what it saw: the progress of a diagonal block
+// beyond the row waited for lets the caller go on without asking again
+__device__ __forceinline__ int flow_wait_value(const int* f, int want, int* info_h, int* s_val)
+{
+    if (threadIdx.x == 0) {
+        int spins = 0, v;
+        while ((v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want && ++spins < FLOW_SPIN_LIMIT) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((spins & 1023) == 0 && __hip_atomic_load(info_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) break;
+        }
+        if (spins >= FLOW_SPIN_LIMIT) __hip_atomic_store(info_h, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_val = v < want ? want : v;      // gave up: go on (the call fails with info < 0)
+    }
+    __syncthreads();
+    return *s_val;
+}
+
+// rows 16 b .. 16 b + 15 of Dinv_col, columns 0 .. 16 b + 15: b + 1 values per thread, past the L1
+__device__ __forceinline__ void dinv_rows_load(const double* __restrict__ Dk, int b, double (&dv)[4])
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (m <= b) {
+            const int e = threadIdx.x + 256 * m;
+            dv[m] = __hip_atomic_load(Dk + (16 * b + e / (16 * (b + 1))) * NB + e % (16 * (b + 1)), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+        }
+}
+
 // panel solve of the tile held in R (LDS, [64][LDP]) against Dinv_col, block column by block column behind the
-// diagonal workgroup's progress flag; B is scratch for the published rows
-// (the solved quarters leave for `dst` as they are formed; DIAG: see below, Q = [64][18] scratch)
+// diagonal workgroup's progress flag; B is scratch for the published rows.  The solved quarters leave for `dst` as
+// they are formed.  When the diagonal block is further along than the row asked for (for most tiles it is long
+// done), the remaining rows are fetched without asking again, each during the products of the one before.
+// DIAG: see below, Q = [64][18] scratch.
 template <bool DIAG>
 __device__ __forceinline__ void flow_trsm(const double* R, double* B, const double* __restrict__ Dk, const int* dflag,
-                                          int gen, int* info_h, d4 (&out)[4], double* __restrict__ dst, double* Q, d4 (&a1)[4],
-                                          int wave, int g, int li)
+                                          int gen, int* info_h, int* s_val, d4 (&out)[4], double* __restrict__ dst, double* Q,
+                                          d4 (&a1)[4], int wave, int g, int li)
 {
-    for (int b = 0; b < 4; ++b) {
-        flow_wait(dflag, 8 * gen + b + 1, info_h);
-        double dv[4];
+    int have = 0;                          // block rows of Dinv_col known to be published
+    double dv[4], dn[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (m <= b) {
-                const int e = threadIdx.x + 256 * m;
-                dv[m] = __hip_atomic_load(Dk + (16 * b + e / (16 * (b + 1))) * NB + e % (16 * (b + 1)), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-            }
+    for (int b = 0; b < 4; ++b) {
+        if (b >= have) {
+            have = flow_wait_value(dflag, 8 * gen + b + 1, info_h, s_val) - 8 * gen;
+            dinv_rows_load(Dk, b, dv);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) dv[m] = dn[m];
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
             if (m <= b) {
@@ -831,6 +880,7 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
                 B[(16 * b + e / (16 * (b + 1))) * LDP + e % (16 * (b + 1))] = dv[m];
             }
         __syncthreads();
+        if (b + 1 < 4 && b + 1 < have) dinv_rows_load(Dk, b + 1, dn);
         out[b] = (d4){0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < 16 * (b + 1); k0 += 4)
             out[b] = MFMA_F64(R[(16 * wave + li) * LDP + k0 + g], B[(16 * b + li) * LDP + k0 + g], out[b]);
@@ -848,90 +898,98 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) a1[nt] = MFMA_F64(a, Q[(16 * nt + li) * 18 + k0 + g], a1[nt]);
             }
+            if (b < 3) __syncthreads();    // Q is rewritten by the next quarter (which may not wait any more)
         }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, double* __restrict__ Dinv,
-                                                   int* __restrict__ info, double* __restrict__ rhs,
-                                                   double* __restrict__ diagL, int* __restrict__ lflags,
-                                                   int* __restrict__ dflags, unsigned* __restrict__ tickets,
-                                                   unsigned ticket_base, int Np, int nh, int gen)
+// one history step of a chunk: a0 -= L_i,k L_lo,k^T, a1 -= L_i,k L_hi,k^T (DIAG: L_hi,k is L_i,k).  In: tA = L_i,k and
+// tB = L_lo,k (requested earlier); MORE: out, the same for step k + 1, requested during this step's products.
+template <bool DIAG, bool MORE>
+__device__ __forceinline__ void flow_step(double* A, double* B, const double* pi, const double* pl, const double* ph,
+                                          d2 (&tA)[8], d2 (&tB)[8], d4 (&a0)[4], d4 (&a1)[4], int wave, int g, int li)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* A = smem;              // [64][LDP]
-    double* B = smem + NB * LDP;   // [64][LDP]
-    double* T16 = B + NB * LDP;    // [4][16][18]
+    planes_to_lds(tA, A, wave, g, li);
+    planes_to_lds(tB, B, wave, g, li);
+    __syncthreads();
+    if (MORE) load_tile_sc1_p(pi + LEAN_TILE, tA);
+    if (!DIAG) load_tile_sc1_p(ph, tB);
+    else if (MORE) load_tile_sc1_p(pl + LEAN_TILE, tB);
+    mma_tile_64(A, B, a0, wave, g, li, true);
+    if (DIAG) {
+        mma_tile_64(A, A, a1, wave, g, li, true);
+    } else {
+        __syncthreads();
+        planes_to_lds(tB, B, wave, g, li);
+        __syncthreads();
+        if (MORE) load_tile_sc1_p(pl + LEAN_TILE, tB);
+        mma_tile_64(A, B, a1, wave, g, li, true);
+    }
+    __syncthreads();                                                         // A and B are rewritten next step
+}
+
+// the tiles (i, lo), (i, hi) of one work item (lo = hi - 1; lo < 0: tile (i, 0) alone); DIAG: (i, hi) is the diagonal tile
+template <bool DIAG>
+__device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, double* __restrict__ row, double* __restrict__ Lh,
+                                           double* __restrict__ Dh, const int* lf, int* lf_row, int* df, int* info_h,
+                                           double* __restrict__ diag_out, int i, int lo, int hi, int nblk, int gen)
+{
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    // Work is handed out by TICKET, not by blockIdx: a workgroup that holds ticket t is running, and every ticket
-    // below t was taken by a workgroup that is running or done -- the order the deadlock argument above needs, by
-    // construction rather than by the dispatcher's habits.  Draws fastest: the diagonal workgroups of all draws first.
-    __shared__ unsigned s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(tickets, 1u) - ticket_base;
-    __syncthreads();
-    const int h = (int)(s_ticket % (unsigned)nh);
-    const int nblk = Np / NB;
-    // ticket / nh -> (block row i, chunk c): rows 0 .. nblk-1 have (i + 2) / 2 chunks, the right-hand-side rows
-    // (i = nblk, tiles 0 .. nblk-1) (nblk + 1) / 2
-    int i = 0, c = (int)(s_ticket / (unsigned)nh);
-    for (;;) {
-        const int nc = (i < nblk) ? (i + 2) / 2 : (nblk + 1) / 2;
-        if (c < nc) break;
-        c -= nc;
-        ++i;
-    }
-    const bool is_rhs = (i == nblk);
-    const int last = is_rhs ? nblk - 1 : i;                       // last tile column of this row
-    const int ncr = (last + 2) / 2;
-    const int hi = last - 2 * (ncr - 1 - c);                     // this chunk: columns hi - 1 (if >= 0) and hi
-    const int lo = hi - 1;
     const bool two = lo >= 0;
-    double* Lh = Lt + (size_t)h * Np * Np;
-    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
-    int* info_h = info + h;
-    const int* lf = lflags + (size_t)h * (nblk + 1) * nblk;     // [row][col]
-    int* lf_row = lflags + ((size_t)h * (nblk + 1) + i) * nblk;
-    int* df = dflags + (size_t)h * nblk;
-    double* Dh = Dinv + (size_t)h * nblk * NB * NB;
-
+    __shared__ int s_n, s_val;
     d4 a0[4], a1[4], st[4];
     if (two) load_tile(row + (size_t)lo * LEAN_TILE, a0);
     load_tile(row + (size_t)hi * LEAN_TILE, a1);
-    // ---- 1. history: steps k < first column of the chunk ----
-    const int first = two ? lo : hi;
-    for (int k = 0; k < first; ++k) {
-        flow_wait(lf_row + k, 8 * gen, info_h);                                  // L_ik (an earlier chunk of this row)
-        load_tile_sc1(row + (size_t)k * LEAN_TILE, st);
-        acc_tile_to_lds(st, A, wave, g, li);
-        if (two) {
-            flow_wait(lf + (size_t)lo * nblk + k, 8 * gen, info_h);              // L_lo,k (a row above); the barrier also covers A
-            load_tile_sc1(Lh + ((size_t)lo * nblk + k) * LEAN_TILE, st);
-            acc_tile_to_lds(st, B, wave, g, li);
-            __syncthreads();
-            mma_tile_64(A, B, a0, wave, g, li, true);
-            __syncthreads();
+    // ---- 1. history: steps k < lo (a chunk with history has two tiles) ----
+    // Step k needs L_ik (an earlier chunk of this row), L_lo,k and -- unless (i,hi) is the diagonal tile, whose second
+    // operand is L_ik again -- L_hi,k (rows above).  One wave looks at the flags of the next FLOW_BATCH steps at once (a
+    // lane per flag) and the workgroup then takes every step that is ready without asking again, the tiles of step
+    // k + 1 in flight during the products of step k: far behind the diagonal workgroups -- where most of the work is
+    // -- a step costs its two products; next to them, one look and one round of loads instead of three of each.
+    const int first = two ? lo : 0;
+#pragma unroll 1
+    for (int k = 0; k < first;) {
+        if (wave == 0) {
+            const int sl = lane / 3, w = lane - 3 * sl, kk = k + sl;
+            const bool live = sl < FLOW_BATCH && kk < first && !(w == 2 && DIAG);
+            const int* fp = (w == 0) ? lf_row + kk : lf + (size_t)(w == 1 ? lo : hi) * nblk + kk;
+            int n = 0, spins = 0;
+            for (;;) {
+                const int f = live ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+                const unsigned long long late = ~__ballot(f >= 8 * gen);
+                n = late ? (__ffsll((long long)late) - 1) / 3 : FLOW_BATCH;     // steps whose flags are all up, from k on
+                if (n > 0) break;
+                if (++spins >= FLOW_SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(info_h, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    n = 1;                 // gave up: go on (the call fails with info < 0)
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                if ((spins & 1023) == 0 && __hip_atomic_load(info_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) { n = 1; break; }
+            }
+            if (lane == 0) s_n = min(n, min(FLOW_BATCH, first - k));
         }
-        if (!is_rhs && hi == i) {                                            // the diagonal tile: L_hi,k is L_ik
-            if (!two) __syncthreads();
-            mma_tile_64(A, A, a1, wave, g, li, true);
-        } else {
-            flow_wait(lf + (size_t)hi * nblk + k, 8 * gen, info_h);
-            load_tile_sc1(Lh + ((size_t)hi * nblk + k) * LEAN_TILE, st);
-            acc_tile_to_lds(st, B, wave, g, li);
-            __syncthreads();
-            mma_tile_64(A, B, a1, wave, g, li, true);
-        }
-        __syncthreads();                                                     // A and B are rewritten next step
+        __syncthreads();
+        const int n = s_n;
+        // two tiles in flight, each requested one product before it is needed
+        d2 tA[8], tB[8];
+        const double* pi = row + (size_t)k * LEAN_TILE;                      // L_i,k   L_lo,k   L_hi,k
+        const double* pl = Lh + ((size_t)lo * nblk + k) * LEAN_TILE;
+        const double* ph = Lh + ((size_t)hi * nblk + k) * LEAN_TILE;
+        load_tile_sc1_p(pi, tA);
+        load_tile_sc1_p(pl, tB);
+#pragma unroll 1
+        for (int s = 0; s + 1 < n; ++s, pi += LEAN_TILE, pl += LEAN_TILE, ph += LEAN_TILE)
+            flow_step<DIAG, true>(A, B, pi, pl, ph, tA, tB, a0, a1, wave, g, li);
+        flow_step<DIAG, false>(A, B, pi, pl, ph, tA, tB, a0, a1, wave, g, li);
+        k += n;
     }
     // ---- 2. tile (i, lo): always a panel tile (lo < hi <= i) ----
-    const bool diag = !is_rhs && hi == i;
     if (two) {
         acc_tile_to_lds(a0, A, wave, g, li);
-        if (diag) {
-            flow_trsm<true>(A, B, Dh + (size_t)lo * NB * NB, df + lo, gen, info_h, st, row + (size_t)lo * LEAN_TILE, T16, a1, wave, g, li);
-        } else {
-            flow_trsm<false>(A, B, Dh + (size_t)lo * NB * NB, df + lo, gen, info_h, st, row + (size_t)lo * LEAN_TILE, T16, a1, wave, g, li);
+        flow_trsm<DIAG>(A, B, Dh + (size_t)lo * NB * NB, df + lo, gen, info_h, &s_val, st, row + (size_t)lo * LEAN_TILE, T16, a1, wave, g, li);
+        if (!DIAG) {
             // step lo of tile (i, hi): with the tile just solved as the row operand
             __syncthreads();                                                 // every wave is done with R
             acc_tile_to_lds(st, A, wave, g, li);
@@ -949,15 +1007,66 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     // ---- 3. tile (i, hi) ----
     acc_tile_to_lds(a1, A, wave, g, li);
     __syncthreads();
-    if (diag) {
-        diag_block<true>(A, B, T16, info_h, i * NB, nullptr, 0, Dh + (size_t)i * NB * NB, diagL + (size_t)h * Np + (size_t)i * NB,
-                         df + i, 8 * gen);
+    if (DIAG) {
+        diag_block<true>(A, B, T16, info_h, i * NB, nullptr, 0, Dh + (size_t)i * NB * NB, diag_out, df + i, 8 * gen);
     } else {
-        flow_trsm<false>(A, B, Dh + (size_t)hi * NB * NB, df + hi, gen, info_h, st, row + (size_t)hi * LEAN_TILE, T16, a1, wave, g, li);
+        flow_trsm<false>(A, B, Dh + (size_t)hi * NB * NB, df + hi, gen, info_h, &s_val, st, row + (size_t)hi * LEAN_TILE, T16, a1, wave, g, li);
         drain_stores();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(lf_row + hi, 8 * gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+__global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, double* __restrict__ Dinv,
+                                                   int* __restrict__ info, double* __restrict__ rhs,
+                                                   double* __restrict__ diagL, int* __restrict__ lflags,
+                                                   int* __restrict__ dflags, unsigned* __restrict__ tickets,
+                                                   unsigned ticket_base, int Np, int nh, int gen)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;              // [64][LDP]
+    double* B = smem + NB * LDP;   // [64][LDP]
+    double* T16 = B + NB * LDP;    // [4][16][18]
+    // Work is handed out by TICKET, not by blockIdx: a workgroup that holds ticket t is running, and every ticket
+    // below t was taken by a workgroup that is running or done -- the order the deadlock argument above needs, by
+    // construction rather than by the dispatcher's habits.  Draws fastest: the diagonal workgroups of all draws first.
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(tickets, 1u) - ticket_base;
+    __syncthreads();
+    const int h = (int)(s_ticket % (unsigned)nh);
+    const int nblk = Np / NB;
+    // ticket / nh -> work item, COLUMN-major: by last column hi ascending, block row ascending within a column.  Block row
+    // i (the right-hand-side rows: i = nblk, tiles 0 .. nblk-1) is cut into pairs of columns from its right end, so its
+    // items have hi = last, last - 2, ...: the items of column hi are the rows i >= hi of hi's parity (and the
+    // right-hand-side rows when nblk - 1 has it).  An item's history is as long as its column index and is wanted when
+    // the diagonal workgroups get there: in this order the workgroups that hold a place on the chip are the ones whose
+    // columns come next -- they run through their history at full speed and leave -- where a row-major order fills the
+    // chip with the right-hand ends of a few rows, each waiting a block column's time for every step.
+    int hi = 0, i;
+    {
+        int c = (int)(s_ticket / (unsigned)nh);
+        for (;; ++hi) {
+            const int nrow = (nblk - 1 - hi) / 2 + 1;                        // rows hi, hi + 2, ... <= nblk - 1
+            const int cnt = nrow + (((nblk - 1 - hi) & 1) == 0 ? 1 : 0);     // + the right-hand-side rows
+            if (c < cnt) { i = (c < nrow) ? hi + 2 * c : nblk; break; }
+            c -= cnt;
+        }
+    }
+    const bool is_rhs = (i == nblk);
+    const int lo = hi - 1;                                               // this item: columns hi - 1 (if >= 0) and hi
+    double* Lh = Lt + (size_t)h * Np * Np;
+    double* row = is_rhs ? rhs + (size_t)h * nblk * LEAN_TILE : Lh + (size_t)i * nblk * LEAN_TILE;   // tiles (i, .)
+    int* info_h = info + h;
+    const int* lf = lflags + (size_t)h * (nblk + 1) * nblk;     // [row][col]
+    int* lf_row = lflags + ((size_t)h * (nblk + 1) + i) * nblk;
+    int* df = dflags + (size_t)h * nblk;
+    double* Dh = Dinv + (size_t)h * nblk * NB * NB;
+
+    const bool diag = !is_rhs && hi == i;
+    // the two kinds of chunk as two straight-line bodies (one body with the distinction inside costs the register
+    // allocator 110 registers more than either)
+    if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL + (size_t)h * Np + (size_t)i * NB, i, lo, hi, nblk, gen);
+    else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen);
 }
 
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
