@@ -1,5 +1,6 @@
 """Dev tool: spx_gp_logprob wall time per call with the in-tree libspx.so against variant builds of it (paths given).
-   python scripts/dev/lib_ab.py _variants/libspx_x.so [...]      (each library runs in its own process)"""
+   python scripts/dev/lib_ab.py _variants/libspx_x.so | NAME=VALUE [...]      (each variant runs in its own process; NAME=VALUE:
+   the in-tree library with that environment variable)"""
 import os, sys, subprocess, json
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(os.path.dirname(here))
@@ -9,10 +10,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import numpy as np
     from spearmint_amd.engine import Engine
     from spearmint_amd.synthetic import synthetic_problem
-    eng = Engine(0, lib=sys.argv[2] if sys.argv[2] != "-" else None)
+    eng = Engine(0, lib=sys.argv[2] if sys.argv[2] != "-" and "=" not in sys.argv[2] else None)
     out = {}
-    for N, D in ((2048, 32), (1000, 16)):
-        for H in (1, 2, 4, 6, 8, 12):
+    for N, D in ((2048, 32), (1000, 16), (512, 8), (4096, 32)):
+        for H in (1, 2, 4, 6, 8, 12, 20, 32):
+            if N == 4096 and H > 4: continue
             comp, cand, vals, hypers = synthetic_problem(N, 16, D, H, 5)
             eng.set_observations(comp, vals)
             eng.set_hypers(hypers); r = eng.gp_logprob()
@@ -29,7 +31,9 @@ libs = ["-"] + sys.argv[1:]
 res = []
 for rnd in range(2):
     for lib in libs:
-        o = subprocess.check_output([sys.executable, os.path.abspath(__file__), "--child", lib]).decode().strip().splitlines()[-1]
+        env = dict(os.environ)
+        if "=" in lib: env[lib.split("=")[0]] = lib.split("=")[1]
+        o = subprocess.check_output([sys.executable, os.path.abspath(__file__), "--child", lib], env=env).decode().strip().splitlines()[-1]
         res.append((lib, json.loads(o)))
 keys = list(res[0][1].keys())
 for k in keys:

@@ -1070,12 +1070,17 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
 }
 
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
-                      int* dflags, unsigned* tickets, unsigned* ticket_base, int Np, int nh, int gen)
+                      int* dflags, unsigned* tickets, unsigned* ticket_base, int Np, int nh, int gen, bool alone)
 {
     const int nblk = Np / NB;
     int ny = (nblk + 1) / 2;                                   // the right-hand-side rows
     for (int i = 0; i < nblk; ++i) ny += (i + 2) / 2;
-    const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
+    // 74.5 KB: two workgroups per CU.  `alone`: ask for more than half of a CU's 160 KB, so that every workgroup has its
+    // CU to itself -- a diagonal block's dependent MFMA chain runs a third slower beside a neighbour whose products
+    // keep the matrix pipes busy (each of its MFMAs then waits for one of theirs to drain), and as long as the chip is
+    // not short of workgroups the whole call follows the diagonal blocks (spx_api.hip decides)
+    size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);
+    if (alone) lds = 96 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_lean_flow, dim3(nh * ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, tickets,
                        *ticket_base, Np, nh, gen);

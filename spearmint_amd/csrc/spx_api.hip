@@ -174,6 +174,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
+    if (!strcmp(name, "lean_flow_cu")) {   // k_lean_flow: one workgroup per CU (1), two (0), by size (-1, default)
+        h->lean_flow_cu = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
     if (!strcmp(name, "lean_flow")) {   // log-likelihood path: the whole factorisation as ONE data-flow launch (1, default), one launch per block column (0)
         h->lean_flow = value < 0 ? -1 : (value != 0);
         return SPX_OK;
@@ -369,6 +373,11 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         dflags = lflags + (size_t)nh * (nblk + 1) * nblk;
     }
     h->flow_used = flow != 0;
+    // One workgroup per CU while the call is bound by the chain of diagonal blocks rather than by the products (option
+    // lean_flow_cu: 1 / 0 / -1 = by size).  Measured (scripts/dev/lib_ab.py), alone against shared: N = 2048: -7 % at 2
+    // draws, -14 % at 4, -9 % at 6, -3 % at 8, +16 % at 12; N = 1000: -4 ... -12 % up to 12 draws, +6 % at 32; N = 4096:
+    // -10 % / -5 % at 1 / 2 draws, +12 % at 4; N = 512: level, -10 % from 20 draws.  The rule below separates the two sides.
+    const bool flow_alone = h->lean_flow_cu >= 0 ? h->lean_flow_cu != 0 : (double)nh * nblk * sqrt((double)nblk) <= 1500.0;
     // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
     // so y = L^-1 (vals - mean) is ready when the last column is
     double* rhs = nullptr;
@@ -385,7 +394,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         h->lean_tiled = rl != 0;
     }
     if (flow)
-        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), lflags, dflags, tickets, &h->flow_ticket_base, Np, nh, h->flow_gen));
+        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), lflags, dflags, tickets, &h->flow_ticket_base, Np, nh, h->flow_gen, flow_alone));
     for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {
             TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));

@@ -341,8 +341,9 @@ def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
         assert np.isclose(big[h], ref, rtol=1e-11)
     # ... nor on whether the factorisation is ONE data-flow launch (k_lean_flow, the default) or one launch per block column
     try:
-        for flow in (1, 0):
+        for flow, cu in ((1, 1), (1, 0), (0, -1)):      # (cu: one workgroup per CU or two, by default chosen from the size)
             eng.set_option("lean_flow", flow)
+            eng.set_option("lean_flow_cu", cu)
             for lo, hi in ((0, 1), (1, 6), (6, 38), (20, 40)):
                 eng.set_hypers(hypers[lo:hi])
                 assert np.array_equal(eng.gp_logprob(), big[lo:hi])
