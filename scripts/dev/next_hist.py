@@ -19,8 +19,9 @@ def set_hypers(self, h, *a, **k):
     last[0] = len(h); return orig_set(self, h, *a, **k)
 def gp_logprob(self, *a, **k):
     t = time.time(); r = orig_lp(self, *a, **k); tsum[last[0]] += time.time() - t; hist[last[0]] += 1; return r
+extra = ("," + sys.argv[1]) if len(sys.argv) > 1 else ""
 for rep in range(2):
-    ch = GPEIOptChooser.init(tempfile.mkdtemp(), "burnin=2,use_multiprocessing=0,mcmc_iters=20,grid_subset=20")
+    ch = GPEIOptChooser.init(tempfile.mkdtemp(), "burnin=2,use_multiprocessing=0,mcmc_iters=20,grid_subset=20" + extra)
     npr.seed(3)
     ch.engine().set_observations(comp, vals)
     if rep == 1:
@@ -29,4 +30,4 @@ for rep in range(2):
     job = ch.next(grid, values, durations, candidates, pending, complete)
     print("next() %.3f s  (job %s)" % (time.time() - t, str(job)[:60]))
 print("log-likelihood calls by batch size: " + "  ".join("%d: %d (%.0f ms)" % (k, hist[k], tsum[k] * 1e3) for k in sorted(hist)))
-print("total %d calls, %.3f s" % (sum(hist.values()), sum(tsum.values())))
+print(extra, "total %d calls, %.3f s" % (sum(hist.values()), sum(tsum.values())))

@@ -24,6 +24,7 @@
 // k_trinv: W = L^-1 by block columns (one launch), stored transposed
 //   WT[j][i] = W[i][j]  so the predict GEMM reads both operands K-major.
 #include "common.h"
+#include "cov_device.h"
 
 #define NB SPX_NB
 #define LDP 66   // LDS row stride (doubles) for MFMA operand tiles: 16 rows x 2 cols hit 32 distinct 8-byte banks
@@ -928,19 +929,100 @@ __device__ __forceinline__ void flow_step(double* A, double* B, const double* pi
     __syncthreads();                                                         // A and B are rewritten next step
 }
 
+// Tile (I, J) of K(X,X) + noise, built where it is consumed: the Gram term on the matrix pipe, the correlation function
+// on the accumulators, in the accumulator layout of the tile storage -- k_cov's MODE 3 body for one 64x64 tile (same
+// helpers, same order of the contraction: the same bits), so that the log-likelihood path has no covariance launch and
+// the matrix never travels through memory before it is factored.  Xh / X2h: x / ls and 2 x / ls of the draw ([Np][Dp]),
+// s1h: row norms.
+struct FlowCov {
+    const double* Xs; const double* X2s; const double* s1; const double* htab;   // null Xs: the tiles are in memory (k_cov ran)
+    int N, Dp, kind;
+};
+
+template <int KIND>
+__device__ __forceinline__ void flow_cov_tile_kind(const double* __restrict__ Xh, const double* __restrict__ X2h,
+                                                   const double* __restrict__ s1h, double amp2, double noise, int N, int Dp,
+                                                   int I, int J, d4 (&acc)[4])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int j0 = NB * I + 16 * wave, c0 = NB * J, Q = Dp >> 2;
+    double s2v[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        s2v[nt] = s1h[c0 + 16 * nt + li];
+        acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    const double* pa = Xh + (size_t)(j0 + li) * Dp + g * Q;
+    const double* pb = X2h + (size_t)(c0 + li) * Dp + g * Q;
+    // the fragments of up to 8 contraction steps are requested together (one round of memory latency per tile for
+    // D <= 32), the products follow in k_cov's order
+    for (int q0 = 0; q0 < Q; q0 += 8) {
+        double af[8], bf[4][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q0 + q < Q) {
+                af[q] = pa[q0 + q];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bf[nt][q] = pb[(size_t)16 * nt * Dp + q0 + q];
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q0 + q < Q) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = MFMA_F64(af[q], bf[nt][q], acc[nt]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + g + 4 * r;
+        const double s1v = s1h[j];
+        double gv[4], cv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) gv[nt] = acc[nt][r];
+        corr_of_kind<KIND, 4>(gv, s1v, s2v, cv);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma clang fp contract(off)
+            const int c = c0 + 16 * nt + li;
+            const double eye = (j == c) ? 1.0 : 0.0;
+            double v = amp2 * (cv[nt] + 1e-6 * eye) + noise * eye;
+            if (j >= N || c >= N) v = eye;
+            acc[nt][r] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void flow_cov_tile(const FlowCov& cv, int h, int Np, int I, int J, d4 (&acc)[4])
+{
+    const double* Xh = cv.Xs + (size_t)h * Np * cv.Dp;
+    const double* X2h = cv.X2s + (size_t)h * Np * cv.Dp;
+    const double* s1h = cv.s1 + (size_t)h * Np;
+    const double noise = cv.htab[h * SPX_HT + 1], amp2 = cv.htab[h * SPX_HT + 2];
+    if (cv.kind == SPX_COV_MATERN32) flow_cov_tile_kind<SPX_COV_MATERN32>(Xh, X2h, s1h, amp2, noise, cv.N, cv.Dp, I, J, acc);
+    else if (cv.kind == SPX_COV_ARDSE) flow_cov_tile_kind<SPX_COV_ARDSE>(Xh, X2h, s1h, amp2, noise, cv.N, cv.Dp, I, J, acc);
+    else flow_cov_tile_kind<SPX_COV_MATERN52>(Xh, X2h, s1h, amp2, noise, cv.N, cv.Dp, I, J, acc);
+}
+
 // the tiles (i, lo), (i, hi) of one work item (lo = hi - 1; lo < 0: tile (i, 0) alone); DIAG: (i, hi) is the diagonal tile
 template <bool DIAG>
 __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, double* __restrict__ row, double* __restrict__ Lh,
                                            double* __restrict__ Dh, const int* lf, int* lf_row, int* df, int* info_h,
-                                           double* __restrict__ diag_out, int i, int lo, int hi, int nblk, int gen)
+                                           double* __restrict__ diag_out, int i, int lo, int hi, int nblk, int gen,
+                                           const FlowCov& cov, int h, bool is_rhs)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     const bool two = lo >= 0;
     __shared__ int s_n, s_val;
     d4 a0[4], a1[4], st[4];
-    if (two) load_tile(row + (size_t)lo * LEAN_TILE, a0);
-    load_tile(row + (size_t)hi * LEAN_TILE, a1);
+    if (cov.Xs && !is_rhs) {
+        if (two) flow_cov_tile(cov, h, nblk * NB, i, lo, a0);
+        flow_cov_tile(cov, h, nblk * NB, i, hi, a1);
+    } else {
+        if (two) load_tile(row + (size_t)lo * LEAN_TILE, a0);
+        load_tile(row + (size_t)hi * LEAN_TILE, a1);
+    }
     // ---- 1. history: steps k < lo (a chunk with history has two tiles) ----
     // Step k needs L_ik (an earlier chunk of this row), L_lo,k and -- unless (i,hi) is the diagonal tile, whose second
     // operand is L_ik again -- L_hi,k (rows above).  One wave looks at the flags of the next FLOW_BATCH steps at once (a
@@ -1021,7 +1103,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
                                                    int* __restrict__ info, double* __restrict__ rhs,
                                                    double* __restrict__ diagL, int* __restrict__ lflags,
                                                    int* __restrict__ dflags, unsigned* __restrict__ tickets,
-                                                   unsigned ticket_base, int Np, int nh, int gen)
+                                                   unsigned ticket_base, int Np, int nh, int gen, FlowCov cov)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;              // [64][LDP]
@@ -1065,13 +1147,15 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     const bool diag = !is_rhs && hi == i;
     // the two kinds of chunk as two straight-line bodies (one body with the distinction inside costs the register
     // allocator 110 registers more than either)
-    if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL + (size_t)h * Np + (size_t)i * NB, i, lo, hi, nblk, gen);
-    else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen);
+    if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL + (size_t)h * Np + (size_t)i * NB, i, lo, hi, nblk, gen, cov, h, is_rhs);
+    else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs);
 }
 
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
-                      int* dflags, unsigned* tickets, unsigned* ticket_base, int Np, int nh, int gen, bool alone)
+                      int* dflags, unsigned* tickets, unsigned* ticket_base, int Np, int nh, int gen, bool alone,
+                      const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind)
 {
+    FlowCov cov{Xs, X2s, s1, htab, N, Dp, kind};
     const int nblk = Np / NB;
     int ny = (nblk + 1) / 2;                                   // the right-hand-side rows
     for (int i = 0; i < nblk; ++i) ny += (i + 2) / 2;
@@ -1083,7 +1167,7 @@ void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double
     if (alone) lds = 96 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_lean_flow, dim3(nh * ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, tickets,
-                       *ticket_base, Np, nh, gen);
+                       *ticket_base, Np, nh, gen, cov);
     *ticket_base += (unsigned)(nh * ny);                       // every workgroup takes exactly one ticket
 }
 

@@ -174,6 +174,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
+    if (!strcmp(name, "lean_flow_cov")) {  // k_lean_flow builds K(X,X) tile by tile itself (1, default) or reads k_cov's (0)
+        h->lean_flow_cov = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
     if (!strcmp(name, "lean_flow_cu")) {   // k_lean_flow: one workgroup per CU (1), two (0), by size (-1, default)
         h->lean_flow_cu = value < 0 ? -1 : (value != 0);
         return SPX_OK;
@@ -341,7 +345,18 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // tile-major copy of the matrix: one-step-deep launches instead of k sequential steps per tile, the
     // diagonal block factored inside the update launch (k_lean_step); same accumulation order, same bits.
     const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
-    TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, rl != 0, dev_kind(h)));
+    // k_lean_flow builds the tiles of K(X,X) itself, where they are consumed (option lean_flow_cov = 0: k_cov does, as for
+    // every other path)
+    const int flow = (rl && h->lean_flow != 0) ? 1 : 0;
+    // (how busy the launch will be: draws x block columns^1.5 -- the two rules below were read off scripts/dev/lib_ab.py)
+    const double flow_load = (double)nh * nblk * sqrt((double)nblk);
+    const bool flow_alone = h->lean_flow_cu >= 0 ? h->lean_flow_cu != 0 : flow_load <= 1500.0;
+    // In the launch: -4 ... -10 % per call (N = 2048: 1-2 draws and from 12; N <= 1000; no k_cov launch, no round trip of
+    // the matrix through memory), except where every workgroup has a CU to itself and the CUs are about to run out
+    // (N = 2048: 6-8 draws, +2 ... +4 %): there the covariance stays a launch of its own.
+    const bool cov_in_flow = flow && (h->lean_flow_cov >= 0 ? h->lean_flow_cov != 0 : !(flow_alone && flow_load > 1000.0));
+    if (!cov_in_flow)
+        TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, rl != 0, dev_kind(h)));
     // Trailing updates two block columns at a time (k_lean_step2) halve the traffic of the trailing matrices but
     // put a second MFMA step in front of every other diagonal block; that pays once the lower triangles of the
     // batch no longer fit the 256 MB Infinity Cache (measured: N=2048 from ~20 draws, N=4096 from 6; -3 ... -16 %),
@@ -356,7 +371,6 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // The whole factorisation as ONE data-flow launch (k_lean_flow; option lean_flow, default on): against one launch per
     // block column -20 % per call at N = 2048 (1-4 draws; -8 ... -13 % at 8-32), -10 % at N = 1000, -5 % at N = 256,
     // level below (scripts/dev/flow_ab.py); the same factor bit for bit
-    const int flow = (rl && h->lean_flow != 0) ? 1 : 0;
     int* lflags = nullptr; int* dflags = nullptr; unsigned* tickets = nullptr;
     if (flow) {
         const size_t nfl = (size_t)nh * (nblk + 1) * nblk + (size_t)nh * nblk + 1;
@@ -376,8 +390,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // One workgroup per CU while the call is bound by the chain of diagonal blocks rather than by the products (option
     // lean_flow_cu: 1 / 0 / -1 = by size).  Measured (scripts/dev/lib_ab.py), alone against shared: N = 2048: -7 % at 2
     // draws, -14 % at 4, -9 % at 6, -3 % at 8, +16 % at 12; N = 1000: -4 ... -12 % up to 12 draws, +6 % at 32; N = 4096:
-    // -10 % / -5 % at 1 / 2 draws, +12 % at 4; N = 512: level, -10 % from 20 draws.  The rule below separates the two sides.
-    const bool flow_alone = h->lean_flow_cu >= 0 ? h->lean_flow_cu != 0 : (double)nh * nblk * sqrt((double)nblk) <= 1500.0;
+    // -10 % / -5 % at 1 / 2 draws, +12 % at 4; N = 512: level, -10 % from 20 draws.  The rule above separates the two sides.
     // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
     // so y = L^-1 (vals - mean) is ready when the last column is
     double* rhs = nullptr;
@@ -394,7 +407,8 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         h->lean_tiled = rl != 0;
     }
     if (flow)
-        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), lflags, dflags, tickets, &h->flow_ticket_base, Np, nh, h->flow_gen, flow_alone));
+        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), lflags, dflags, tickets, &h->flow_ticket_base, Np, nh, h->flow_gen, flow_alone,
+                                             cov_in_flow ? h->Xs.d() : nullptr, h->X2s.d(), h->s1.d(), h->htab.d(), (int)N, Dp, dev_kind(h)));
     for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {
             TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));

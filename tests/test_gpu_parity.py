@@ -341,9 +341,12 @@ def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
         assert np.isclose(big[h], ref, rtol=1e-11)
     # ... nor on whether the factorisation is ONE data-flow launch (k_lean_flow, the default) or one launch per block column
     try:
-        for flow, cu in ((1, 1), (1, 0), (0, -1)):      # (cu: one workgroup per CU or two, by default chosen from the size)
+        # (cu: one workgroup per CU or two, by default chosen from the size; cov: K(X,X) built tile by tile inside the
+        # launch, the default, or by k_cov before it)
+        for flow, cu, cov in ((1, 1, 1), (1, 0, 1), (1, -1, 0), (0, -1, -1)):
             eng.set_option("lean_flow", flow)
             eng.set_option("lean_flow_cu", cu)
+            eng.set_option("lean_flow_cov", cov)
             for lo, hi in ((0, 1), (1, 6), (6, 38), (20, 40)):
                 eng.set_hypers(hypers[lo:hi])
                 assert np.array_equal(eng.gp_logprob(), big[lo:hi])
@@ -368,6 +371,8 @@ def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
         eng.set_option("lean_lazy", -1)
         eng.set_option("lean_ps", -1)
         eng.set_option("lean_flow", -1)
+        eng.set_option("lean_flow_cu", -1)
+        eng.set_option("lean_flow_cov", -1)
 
 
 def _lean_form(eng, form):
