@@ -1348,7 +1348,7 @@ void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab,
 __global__ __launch_bounds__(256) void k_lean_logprob(const double* __restrict__ diagL,
                                                       const double* __restrict__ rhs,
                                                       const int* __restrict__ info,
-                                                      double* __restrict__ out, int N, int Np)
+                                                      double* __restrict__ out, int* __restrict__ info_out, int N, int Np)
 {
     __shared__ double red[2][256];
     const int h = blockIdx.x;
@@ -1369,14 +1369,17 @@ __global__ __launch_bounds__(256) void k_lean_logprob(const double* __restrict__
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0)
-        out[h] = info[h] ? -__builtin_inf() : (-red[0][0] - 0.5 * red[1][0]);
+    if (threadIdx.x == 0) {     // (out / info_out may be pinned host memory: one store each)
+        const int bad = info[h];
+        out[h] = bad ? -__builtin_inf() : (-red[0][0] - 0.5 * red[1][0]);
+        if (info_out) info_out[h] = bad;
+    }
 }
 
-void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int N,
-                         int Np, int nh)
+void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int* info_out,
+                         int N, int Np, int nh)
 {
-    hipLaunchKernelGGL(k_lean_logprob, dim3(nh), dim3(256), 0, s, diagL, rhs, info, out, N, Np);
+    hipLaunchKernelGGL(k_lean_logprob, dim3(nh), dim3(256), 0, s, diagL, rhs, info, out, info_out, N, Np);
 }
 
 // ---------------------------------------------------------------------------

@@ -60,8 +60,8 @@ void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double
                       const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind);
 void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh,
                           int* info, int* flags);
-void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int N,
-                         int Np, int nh);
+void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int* info_out,
+                         int N, int Np, int nh);
 void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh);
 void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
                   double* gamma, int N, int Np, int nh);

@@ -139,6 +139,8 @@ void spx_destroy(spx_handle* h)
                           &h->am_out_val, &h->am_out_idx, &h->scratch, &h->sobol_dirs, &h->sobol_out, &h->rhs, &h->diagL, &h->ps_flags, &h->flow_flags,
                           &h->alphaS, &h->pt_u, &h->rec_send, &h->rec_recv, &h->rec_out, &h->ei_sum_full};
         for (DevBuf* b : bufs) b->release();
+        h->pin_up.release();
+        h->pin_res.release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
         (void)hipEventDestroy(h->ev_t0);
@@ -329,7 +331,11 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     hipStream_t s = h->stream;
     h->ev_used = 0;
     hipEvent_t t0 = h->ev_t0, t1 = h->ev_t1;
-    HIPCHK(hipMemcpyAsync(h->hyp.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice, s));
+    // through pinned memory: a pageable source makes the runtime stage the copy and wait for it (the stream is idle here:
+    // every entry point that queues work on it synchronises before it returns, so the staging buffer is free)
+    if ((rc = h->pin_up.reserve(raw.size() * 8))) return rc;
+    memcpy(h->pin_up.p, raw.data(), raw.size() * 8);
+    HIPCHK(hipMemcpyAsync(h->hyp.p, h->pin_up.p, raw.size() * 8, hipMemcpyHostToDevice, s));
     if (h->timing || !lean) HIPCHK(hipEventRecord(t0, s));
     // the log-likelihood path zeroes info (and the hand-off flags) in its right-hand-side kernel: two stream operations
     // fewer per call
@@ -844,14 +850,23 @@ static int gp_logprob_once(spx_handle* h, double* out)
     int rc = do_factor(h, true, true, true);   // K(X,X), Cholesky, forward solve -- no inverse; queued, not yet synchronised
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
-    if (h->lean_tiled)
-        launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, h->lp.d(), (int)h->N, h->Np, h->H);
-    else
-        launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);
     std::vector<int> info(h->H);
-    HIPCHK(hipMemcpyAsync(out, h->lp.p, (size_t)h->H * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)h->H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->lean_tiled) {
+        // the kernel writes the H values and the H not-PD flags straight into pinned host memory: no device-to-host copies
+        // (two of them, to pageable memory, were 40 us of a 95 us call at N = 64)
+        if ((rc = h->pin_res.reserve((size_t)h->H * 12))) return rc;
+        double* lp_host = (double*)h->pin_res.p;
+        int* info_host = (int*)(lp_host + h->H);
+        launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, lp_host, info_host, (int)h->N, h->Np, h->H);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(out, lp_host, (size_t)h->H * 8);
+        memcpy(info.data(), info_host, (size_t)h->H * sizeof(int));
+    } else {
+        launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);
+        HIPCHK(hipMemcpyAsync(out, h->lp.p, (size_t)h->H * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)h->H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     return finish_factor(h, info, true, true);
 }
 

@@ -49,6 +49,28 @@ struct DevBuf {
     double* d() const { return (double*)p; }
 };
 
+// pinned (page-locked, device-visible) host memory: uploads from it are true asynchronous DMA without a staging copy
+// inside the runtime, and a kernel can write a handful of result words straight into it
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SPX_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        if (bytes < 4096) bytes = 4096;
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+            return fail(SPX_ERR_HIP, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        }
+        cap = bytes;
+        return SPX_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 enum Stage {
     ST_SCALE = 0, ST_COV_SELF, ST_CHOL_DIAG, ST_CHOL_PANEL, ST_TRINV, ST_GAMMA_ALPHA,
     ST_COV_CROSS, ST_CROSS_MEAN, ST_PREDICT_GEMM, ST_EI_FINALIZE, ST_MEAN_ARGMAX,
@@ -110,6 +132,7 @@ struct spx_handle {
     DevBuf flow_flags;                                              // k_lean_flow: [H][nblk + 1][nblk] tile flags + [H][nblk] diagonal progress + the ticket counter
     size_t flow_flags_n = 0;                                        // ints the flags were zeroed for
     int flow_gen = 0;                                               // generation of the last call (flags are compared, not cleared)
+    PinBuf pin_up, pin_res;                                         // hyper-parameter upload staging; log-likelihood results
     bool handoff_timeout = false;                                   // finish_factor saw info < 0
     bool flow_used = false;                                         // the last factorisation ran k_lean_flow
     unsigned flow_ticket_base = 0;                                  // tickets handed out by all earlier calls (the counter is never reset)
