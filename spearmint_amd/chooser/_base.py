@@ -67,9 +67,10 @@ class GPEIBase(object):
         # where the slice sampler's log-likelihood (K build + Cholesky + solve per call) runs:
         # "0" host numpy/scipy (the reference's way), "1" libspx on the GPU, "auto" = GPU once
         # the factorisation outweighs the call latency.  On the MI355X box (scripts/dev/logprob_threshold.py, round 3): a GPU call
-        # costs 0.095 ms up to N = 128 whether it carries one hyper row or six, a host evaluation 0.030 ms at N = 32, 0.049 at
-        # 64, 0.080 at 96, 0.26 at 128; a slice move needs ~4.4 evaluations one after the other on the host or ~1.3 speculative
-        # batches on the GPU: break-even near N = 40, "auto" switches at 64.  (N = 2048: 0.83 ms per GPU call vs 250 ms.)
+        # costs 0.067 ms up to N = 128 whether it carries one hyper row or six (one launch for the factorisation, results
+        # written into pinned host memory), a host evaluation 0.022 ms at N = 8, 0.030 at 32, 0.049 at 64, 0.081 at 96, 0.22
+        # at 128; a slice move needs ~4.4 evaluations one after the other on the host or ~1.3 speculative batches on the GPU:
+        # break-even near N = 10, "auto" switches at 32.  (N = 2048: 0.59 ms per GPU call vs 250 ms.)
         self.gpu_logprob = str(gpu_logprob)
         # same choice for the EI + gradient objective of the local refinement (spx_ei_grad)
         self.gpu_refine = str(gpu_refine)
@@ -150,7 +151,7 @@ class GPEIBase(object):
     # -- log-likelihood data term: host or GPU ------------------------------------------
     def _use_gpu_logprob(self, n):
         if self.gpu_logprob == "auto":
-            return n >= 64
+            return n >= 32
         return _as_bool(self.gpu_logprob)
 
     def _use_gpu_refine(self, n):
