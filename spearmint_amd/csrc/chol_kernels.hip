@@ -794,6 +794,12 @@ __device__ __forceinline__ void load_tile_sc1_p(const double* __restrict__ tile,
     for (int p = 0; p < 8; ++p)
         t[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16 + p * 4096, 0, SPX_SC1));
 }
+__device__ __forceinline__ void load_tile_p(const double* __restrict__ tile, d2 (&t)[8])     // (a tile of an earlier launch)
+{
+    const d2* p = reinterpret_cast<const d2*>(tile) + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = p[q * 256];
+}
 __device__ __forceinline__ void planes_to_lds(const d2 (&t)[8], double* lds, int wave, int g, int li)
 {
 #pragma unroll
@@ -1090,7 +1096,9 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
     acc_tile_to_lds(a1, A, wave, g, li);
     __syncthreads();
     if (DIAG) {
-        diag_block<true>(A, B, T16, info_h, i * NB, nullptr, 0, Dh + (size_t)i * NB * NB, diag_out, df + i, 8 * gen);
+        // (the EI path keeps L_ii -- row-major in its tile's place -- for spx_get_factor; the log-likelihood path only its diagonal)
+        diag_block<true>(A, B, T16, info_h, i * NB, diag_out ? nullptr : row + (size_t)i * LEAN_TILE, NB, Dh + (size_t)i * NB * NB, diag_out,
+                         df + i, 8 * gen);
     } else {
         flow_trsm<false>(A, B, Dh + (size_t)hi * NB * NB, df + hi, gen, info_h, &s_val, st, row + (size_t)hi * LEAN_TILE, T16, a1, wave, g, li);
         drain_stores();
@@ -1129,7 +1137,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
         int c = (int)(s_ticket / (unsigned)nh);
         for (;; ++hi) {
             const int nrow = (nblk - 1 - hi) / 2 + 1;                        // rows hi, hi + 2, ... <= nblk - 1
-            const int cnt = nrow + (((nblk - 1 - hi) & 1) == 0 ? 1 : 0);     // + the right-hand-side rows
+            const int cnt = nrow + ((rhs && ((nblk - 1 - hi) & 1) == 0) ? 1 : 0);   // + the right-hand-side rows (if any)
             if (c < cnt) { i = (c < nrow) ? hi + 2 * c : nblk; break; }
             c -= cnt;
         }
@@ -1147,7 +1155,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     const bool diag = !is_rhs && hi == i;
     // the two kinds of chunk as two straight-line bodies (one body with the distinction inside costs the register
     // allocator 110 registers more than either)
-    if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL + (size_t)h * Np + (size_t)i * NB, i, lo, hi, nblk, gen, cov, h, is_rhs);
+    if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL ? diagL + (size_t)h * Np + (size_t)i * NB : nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs);
     else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs);
 }
 
@@ -1157,7 +1165,7 @@ void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double
 {
     FlowCov cov{Xs, X2s, s1, htab, N, Dp, kind};
     const int nblk = Np / NB;
-    int ny = (nblk + 1) / 2;                                   // the right-hand-side rows
+    int ny = rhs ? (nblk + 1) / 2 : 0;                         // the right-hand-side rows (the EI path has none)
     for (int i = 0; i < nblk; ++i) ny += (i + 2) / 2;
     // 74.5 KB: two workgroups per CU.  `alone`: ask for more than half of a CU's 160 KB, so that every workgroup has its
     // CU to itself -- a diagonal block's dependent MFMA chain runs a third slower beside a neighbour whose products
@@ -1391,6 +1399,9 @@ void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, 
 // WT must be zero-initialised by the caller (entries above the block diagonal
 // inside a 128-wide GEMM row block are read by the predict GEMM).
 // ---------------------------------------------------------------------------
+// TILED: L in the tile-major storage of the log-likelihood path (k_lean_flow factored it): tile (i, p) at
+// (i nblk + p) * 4096 doubles, accumulator order inside
+template <bool TILED>
 __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
                                                const double* __restrict__ Dinv,
                                                double* __restrict__ WT, int Np, int nh)
@@ -1426,17 +1437,22 @@ __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
         __syncthreads();  // orders the previous iteration's WT stores (and LDS reads) before what follows
         {
             TileRegs ta, tb;
+            d2 tp[8];
+            const double* Lrow = Lh + (size_t)ib * nblk * LEAN_TILE;          // TILED: the tiles (ib, .)
             tile_load(Wh + j0 * Np + (size_t)jb * NB, Np, ta);
-            tile_load(Lh + i0 * Np + (size_t)jb * NB, Np, tb);
+            if (TILED) load_tile_p(Lrow + (size_t)jb * LEAN_TILE, tp);
+            else tile_load(Lh + i0 * Np + (size_t)jb * NB, Np, tb);
             for (int p = jb; p < ib; ++p) {
                 double* Ac = A + ((p - jb) & 1) * NB * LDP;
                 double* Bc = B + ((p - jb) & 1) * NB * LDP;
                 tile_store(ta, Ac);
-                tile_store(tb, Bc);
+                if (TILED) planes_to_lds(tp, Bc, wave, g, li);
+                else tile_store(tb, Bc);
                 __syncthreads();
                 if (p + 1 < ib) {
                     tile_load(Wh + j0 * Np + (size_t)(p + 1) * NB, Np, ta);
-                    tile_load(Lh + i0 * Np + (size_t)(p + 1) * NB, Np, tb);
+                    if (TILED) load_tile_p(Lrow + (size_t)(p + 1) * LEAN_TILE, tp);
+                    else tile_load(Lh + i0 * Np + (size_t)(p + 1) * NB, Np, tb);
                 }
                 mma_tile_64(Ac, Bc, acc, wave, g, li, false);
             }
@@ -1460,12 +1476,16 @@ __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
     }
 }
 
-void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh)
+void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh, bool tiled)
 {
     const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trinv),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_trinv, dim3((Np / NB) * nh), dim3(256), lds, s, L, Dinv, WT, Np, nh);
+    if (tiled) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trinv<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_trinv<true>, dim3((Np / NB) * nh), dim3(256), lds, s, L, Dinv, WT, Np, nh);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trinv<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_trinv<false>, dim3((Np / NB) * nh), dim3(256), lds, s, L, Dinv, WT, Np, nh);
+    }
 }
 
 // ---------------------------------------------------------------------------

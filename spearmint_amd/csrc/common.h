@@ -62,7 +62,7 @@ void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab,
                           int* info, int* flags);
 void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int* info_out,
                          int N, int Np, int nh);
-void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh);
+void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT, int Np, int nh, bool tiled = false);
 void launch_gamma(hipStream_t s, const double* WT, const double* vals, const double* htab,
                   double* gamma, int N, int Np, int nh);
 void launch_gamma_multi(hipStream_t s, const double* WT_h, const double* rhs, const double* htab_h,

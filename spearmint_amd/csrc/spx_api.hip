@@ -176,6 +176,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
+    if (!strcmp(name, "ei_flow")) {        // spx_factor through k_lean_flow (1), the left-looking launches (0), by batch size (-1, default)
+        h->ei_flow = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
     if (!strcmp(name, "lean_flow_cov")) {  // k_lean_flow builds K(X,X) tile by tile itself (1, default) or reads k_cov's (0)
         h->lean_flow_cov = value < 0 ? -1 : (value != 0);
         return SPX_OK;
@@ -353,7 +357,13 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
     // k_lean_flow builds the tiles of K(X,X) itself, where they are consumed (option lean_flow_cov = 0: k_cov does, as for
     // every other path)
-    const int flow = (rl && h->lean_flow != 0) ? 1 : 0;
+    // The EI path (spx_factor) takes the same launch when its batch is small enough for it (option ei_flow; up to 32
+    // draws by default): no right-hand-side rows, the diagonal blocks of L kept for spx_get_factor, W = L^-1 from the
+    // tile-major factor (k_trinv<true>).  The same factor bit for bit (per-tile update order and diagonal blocks are
+    // shared with the left-looking kernels), so every EI result stays what it was.
+    const int eflow = (!lean && (h->ei_flow >= 0 ? h->ei_flow != 0 : nh <= 32)) ? 1 : 0;
+    const int flow = ((rl || eflow) && h->lean_flow != 0) ? 1 : 0;
+    const bool tiled = rl || flow;
     // (how busy the launch will be: draws x block columns^1.5 -- the two rules below were read off scripts/dev/lib_ab.py)
     const double flow_load = (double)nh * nblk * sqrt((double)nblk);
     const bool flow_alone = h->lean_flow_cu >= 0 ? h->lean_flow_cu != 0 : flow_load <= 1500.0;
@@ -362,7 +372,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // (N = 2048: 6-8 draws, +2 ... +4 %): there the covariance stays a launch of its own.
     const bool cov_in_flow = flow && (h->lean_flow_cov >= 0 ? h->lean_flow_cov != 0 : !(flow_alone && flow_load > 1000.0));
     if (!cov_in_flow)
-        TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, rl != 0, dev_kind(h)));
+        TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, tiled, dev_kind(h)));
     // Trailing updates two block columns at a time (k_lean_step2) halve the traffic of the trailing matrices but
     // put a second MFMA step in front of every other diagonal block; that pays once the lower triangles of the
     // batch no longer fit the 256 MB Infinity Cache (measured: N=2048 from ~20 draws, N=4096 from 6; -3 ... -16 %),
@@ -412,8 +422,9 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         }
         h->lean_tiled = rl != 0;
     }
+    h->factor_tiled = !lean && flow;
     if (flow)
-        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), lflags, dflags, tickets, &h->flow_ticket_base, Np, nh, h->flow_gen, flow_alone,
+        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, lean ? h->diagL.d() : nullptr, lflags, dflags, tickets, &h->flow_ticket_base, Np, nh, h->flow_gen, flow_alone,
                                              cov_in_flow ? h->Xs.d() : nullptr, h->X2s.d(), h->s1.d(), h->htab.d(), (int)N, Dp, dev_kind(h)));
     for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {
@@ -427,7 +438,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         }
     }
     if (!lean) {
-        TIMED(ST_TRINV, launch_trinv(s, h->Lm.d(), h->Dinv.d(), h->WT.d(), Np, nh));
+        TIMED(ST_TRINV, launch_trinv(s, h->Lm.d(), h->Dinv.d(), h->WT.d(), Np, nh, flow != 0));
         TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d(), h->vals.d(), h->htab.d(), h->gamma.d(), (int)N, Np, H));
         if (nm == 2)
             TIMED(ST_GAMMA_ALPHA, launch_gamma(s, h->WT.d() + (size_t)H * Np * Np, h->ldur.d(),
@@ -476,7 +487,15 @@ int spx_factor(spx_handle* h)
 {
     if (!h) return fail(SPX_ERR_ARG, "spx_factor: null handle");
     if (h->multi) return spx_multi_factor(h->multi);
-    return do_factor(h, false);
+    h->handoff_timeout = false;
+    int rc = do_factor(h, false);
+    if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {   // as in spx_gp_logprob: never seen; bounded, then the launches
+        fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
+        h->lean_flow = 0;
+        h->handoff_timeout = false;
+        rc = do_factor(h, false);
+    }
+    return rc;
 }
 
 int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot)
@@ -785,7 +804,28 @@ int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* al
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy2D(K, (size_t)N * 8, h->scratch.p, (size_t)Np * 8, (size_t)N * 8, (size_t)N, hipMemcpyDeviceToHost));
     }
-    if (L) {
+    if (L && h->factor_tiled) {
+        // tile-major factor (k_lean_flow): tile (I, J) at (I nblk + J) * 4096 doubles; below the diagonal in accumulator
+        // order -- value q = 4 nt + r of thread t at ((q >> 1) * 256 + t) * 2 + (q & 1) is the element
+        // (16 (t >> 6) + ((t & 63) >> 4) + 4 r, 16 nt + (t & 15)) -- the diagonal tiles row-major (diag_block's Lkk)
+        std::vector<double> T(nn);
+        HIPCHK(hipMemcpy(T.data(), h->Lm.d() + (size_t)draw * nn, nn * 8, hipMemcpyDeviceToHost));
+        const int nblk = Np / SPX_NB;
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < N; ++j) {
+                double v = 0.0;
+                if (j <= i) {
+                    const int I = (int)(i >> 6), J = (int)(j >> 6), ri = (int)(i & 63), cj = (int)(j & 63);
+                    const double* tile = T.data() + ((size_t)I * nblk + J) * 4096;
+                    if (I == J) v = tile[ri * 64 + cj];
+                    else {
+                        const int t = (ri >> 4) * 64 + (ri & 3) * 16 + (cj & 15), q = (cj >> 4) * 4 + ((ri & 15) >> 2);
+                        v = tile[((q >> 1) * 256 + t) * 2 + (q & 1)];
+                    }
+                }
+                L[i * N + j] = v;
+            }
+    } else if (L) {
         HIPCHK(hipMemcpy2D(L, (size_t)N * 8, h->Lm.d() + (size_t)draw * nn, (size_t)Np * 8, (size_t)N * 8, (size_t)N,
                            hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < N; ++i)
