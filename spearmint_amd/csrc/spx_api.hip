@@ -176,7 +176,7 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
-    if (!strcmp(name, "ei_flow")) {        // spx_factor through k_lean_flow (1), the left-looking launches (0), by batch size (-1, default)
+    if (!strcmp(name, "ei_flow")) {        // spx_factor through k_lean_flow (1, default), the left-looking launches (0)
         h->ei_flow = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
@@ -357,11 +357,12 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
     // k_lean_flow builds the tiles of K(X,X) itself, where they are consumed (option lean_flow_cov = 0: k_cov does, as for
     // every other path)
-    // The EI path (spx_factor) takes the same launch when its batch is small enough for it (option ei_flow; up to 32
-    // draws by default): no right-hand-side rows, the diagonal blocks of L kept for spx_get_factor, W = L^-1 from the
+    // The EI path (spx_factor) takes the same launch (option ei_flow, default on; measured against the left-looking
+    // launches: factor stage 0.28 -> 0.19 ms at N = 256 x 10 draws, 6.3 -> 3.8 ms at 2048 x 20, 2.3 -> 1.5 ms at
+    // 1024 x 40, 0.85 -> 0.61 ms at 512 x 60): no right-hand-side rows, the diagonal blocks of L kept for spx_get_factor, W = L^-1 from the
     // tile-major factor (k_trinv<true>).  The same factor bit for bit (per-tile update order and diagonal blocks are
     // shared with the left-looking kernels), so every EI result stays what it was.
-    const int eflow = (!lean && (h->ei_flow >= 0 ? h->ei_flow != 0 : nh <= 32)) ? 1 : 0;
+    const int eflow = (!lean && h->ei_flow != 0) ? 1 : 0;
     const int flow = ((rl || eflow) && h->lean_flow != 0) ? 1 : 0;
     const bool tiled = rl || flow;
     // (how busy the launch will be: draws x block columns^1.5 -- the two rules below were read off scripts/dev/lib_ab.py)

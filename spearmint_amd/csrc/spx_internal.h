@@ -127,7 +127,7 @@ struct spx_handle {
     int lean_ps = -1;                                               // option "lean_ps": 0 / 1 / -1 = default (on)
     DevBuf ps_flags;                                                // k_lean_step_ps: progress of every diagonal block, [H][nblk]
     int lean_flow = -1;                                             // option "lean_flow": whole factorisation in one launch (k_lean_flow)
-    int ei_flow = -1;                                               // option "ei_flow": spx_factor through k_lean_flow 1 / 0 / -1 = by batch size
+    int ei_flow = -1;                                               // option "ei_flow": spx_factor through k_lean_flow 1 / 0 / -1 = default (on)
     bool factor_tiled = false;                                      // the EI path's factor is tile-major (k_lean_flow made it)
     int lean_flow_cov = -1;                                         // option "lean_flow_cov": K(X,X) built inside k_lean_flow 1 / 0 / -1 = default (on)
     int lean_flow_cu = -1;                                          // option "lean_flow_cu": one workgroup per CU 1 / 0 / -1 = by size

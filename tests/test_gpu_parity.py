@@ -663,11 +663,11 @@ def test_in_launch_handoff_under_concurrent_load(eng):
 
 
 @pytest.mark.parametrize("N,D,H,per_sec", [(256, 8, 10, False), (1000, 7, 12, False), (70, 3, 5, False),
-                                           (40, 2, 3, False), (520, 6, 20, True), (330, 5, 9, True)])
+                                           (40, 2, 3, False), (520, 6, 20, True), (330, 5, 9, True), (200, 4, 70, False)])
 def test_ei_path_factor_through_the_data_flow_launch(eng, N, D, H, per_sec):
     """spx_factor takes the log-likelihood path's one-launch factorisation (k_lean_flow: no right-hand-side rows, W from
-    the tile-major factor) when the batch is small enough (option ei_flow; default up to 32 draws -- the per-second
-    cases here run 2 H = 40 and 18 through it explicitly).  The factor is the same bit for bit, so EI, its mean, the
+    the tile-major factor; option ei_flow, default on -- the per-second cases here run 2 H = 40 and 18 draws through it,
+    the last one 70).  The factor is the same bit for bit, so EI, its mean, the
     argmax, L and alpha must all be exactly what the left-looking launches give; a not-PD draw is reported alike."""
     prob = synthetic_problem(N, 3000, D, H, 77 + N, per_sec=per_sec)
     res = {}
