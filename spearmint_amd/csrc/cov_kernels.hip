@@ -24,20 +24,23 @@
 //   sumsq[h][row]  = sum_d (x[row][d] / ls[h][d])^2
 // ---------------------------------------------------------------------------
 #define SR_DC 32   // feature columns per LDS pass
+// ROWS rows per workgroup: 256, or 64 when the launch would otherwise be a handful of workgroups (the log-likelihood
+// path: N = 2048 x 6 draws was 48 workgroups and 20 us; the arithmetic per row is the same either way)
+template <int ROWS>
 __global__ __launch_bounds__(256) void k_scale_rows(
     const double* __restrict__ x, int64_t n, int64_t n_pad, int D, int Dp,
     const double* __restrict__ ls, int ls_stride, double factor,
     double* __restrict__ xs, double* __restrict__ sumsq, double* __restrict__ xs2)
 {
 #pragma clang fp contract(off)
-    // 256 rows per workgroup, staged through LDS so that both the read of x (rows of D doubles)
+    // ROWS rows per workgroup, staged through LDS so that both the read of x (rows of D doubles)
     // and the write of xs (rows of Dp doubles) are contiguous across the wave; each thread then
     // owns one row and accumulates its squared norm left to right.
-    __shared__ double T[256][SR_DC + 1];
+    __shared__ double T[ROWS][SR_DC + 1];
     const int tid = threadIdx.x;
     const int h = blockIdx.y;
-    const int64_t row0 = (int64_t)blockIdx.x * 256;
-    const int rows = (int)((n_pad - row0 < 256) ? (n_pad - row0) : 256);
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int rows = (int)((n_pad - row0 < ROWS) ? (n_pad - row0) : ROWS);
     const int64_t row = row0 + tid;
     const double* lsh = ls + (size_t)h * ls_stride;
     double* o = xs + ((size_t)h * n_pad + row0) * Dp;
@@ -78,9 +81,13 @@ void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad,
                        const double* ls, int ls_stride, int nh, double factor,
                        double* xs, double* sumsq, double* xs2)
 {
-    dim3 grid((unsigned)((n_pad + 255) / 256), nh);
-    hipLaunchKernelGGL(k_scale_rows, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride,
-                       factor, xs, sumsq, xs2);
+    if (((n_pad + 255) / 256) * nh < 512) {
+        dim3 grid((unsigned)((n_pad + 63) / 64), nh);
+        hipLaunchKernelGGL(k_scale_rows<64>, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride, factor, xs, sumsq, xs2);
+    } else {
+        dim3 grid((unsigned)((n_pad + 255) / 256), nh);
+        hipLaunchKernelGGL(k_scale_rows<256>, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride, factor, xs, sumsq, xs2);
+    }
 }
 
 #include "cov_device.h"   // sqrt_pos / exp_neg / *_corr: shared with the log-likelihood path's in-kernel covariance (chol_kernels.hip)
