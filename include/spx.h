@@ -227,10 +227,18 @@ const char* spx_timing_name(int i);
 /* options: "covar" (SPX_COVAR_*); tuning knobs "kstar_budget_bytes" (K(X*,X) staging buffer;
  * 0 = default), "streams" (1|2), "timing" (0|1), "gemm_waves" (predict-GEMM variant of THIS
  * handle; values the build does not contain are rejected with SPX_ERR_ARG), and the forms of the
- * log-likelihood factorisation, all bit-identical, -1 = chosen from the sizes: "lean_lazy" (trailing
- * updates one (0) or two (1) block columns at a time), "lean_ps" (1: the panel solve of a block column
- * runs inside the update launch, handed the inverse of the diagonal block behind its pivots; 0: a
- * launch of its own).                                                                            */
+ * factorisation, all bit-identical, -1 = the default / chosen from the sizes:
+ *   "lean_flow"     1 (default): the whole factorisation of spx_gp_logprob is ONE data-flow launch
+ *                   (k_lean_flow: every dependency a hand-off inside the launch); 0: one launch per
+ *                   block column, in the forms selected by "lean_ps" / "lean_lazy";
+ *   "ei_flow"       the same choice for spx_factor (default 1);
+ *   "lean_flow_cu"  k_lean_flow with one workgroup per CU (1) or two (0); -1: by size;
+ *   "lean_flow_cov" k_lean_flow builds the tiles of K(X,X) itself (1) or reads k_cov's (0); -1: by size;
+ *   "lean_lazy"     trailing updates one (0) or two (1) block columns at a time;
+ *   "lean_ps"       1: the panel solve of a block column runs inside the update launch, handed the
+ *                   inverse of the diagonal block behind its pivots; 0: a launch of its own.
+ * If an in-launch hand-off ever times out (its spins are bounded; never observed), the call is
+ * repeated with one launch per block column and the handle stays in that form.                   */
 int spx_set_option(spx_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus
