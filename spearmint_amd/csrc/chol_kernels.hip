@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
                                                    int* __restrict__ info, double* __restrict__ rhs,
                                                    double* __restrict__ diagL, int* __restrict__ lflags,
                                                    int* __restrict__ dflags, unsigned* __restrict__ tickets,
-                                                   unsigned ticket_base, int Np, int nh, int gen, FlowCov cov)
+                                                   int Np, int nh, int gen, FlowCov cov)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;              // [64][LDP]
@@ -1120,8 +1120,10 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     // Work is handed out by TICKET, not by blockIdx: a workgroup that holds ticket t is running, and every ticket
     // below t was taken by a workgroup that is running or done -- the order the deadlock argument above needs, by
     // construction rather than by the dispatcher's habits.  Draws fastest: the diagonal workgroups of all draws first.
+    // (tickets[0]: the counter; tickets[1]: workgroups that are done -- the last one to leave puts both back to zero for
+    // the next launch, so the host keeps no count that a failed launch could put out of step)
     __shared__ unsigned s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(tickets, 1u) - ticket_base;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(tickets, 1u);
     __syncthreads();
     const int h = (int)(s_ticket % (unsigned)nh);
     const int nblk = Np / NB;
@@ -1157,10 +1159,14 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     // allocator 110 registers more than either)
     if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL ? diagL + (size_t)h * Np + (size_t)i * NB : nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs);
     else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs);
+    if (threadIdx.x == 0 && atomicAdd(tickets + 1, 1u) == gridDim.x - 1) {   // everybody else has left (and long since drawn a ticket)
+        __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
-                      int* dflags, unsigned* tickets, unsigned* ticket_base, int Np, int nh, int gen, bool alone,
+                      int* dflags, unsigned* tickets, int Np, int nh, int gen, bool alone,
                       const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind)
 {
     FlowCov cov{Xs, X2s, s1, htab, N, Dp, kind};
@@ -1175,8 +1181,7 @@ void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double
     if (alone) lds = 96 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_lean_flow, dim3(nh * ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, tickets,
-                       *ticket_base, Np, nh, gen, cov);
-    *ticket_base += (unsigned)(nh * ny);                       // every workgroup takes exactly one ticket
+                       Np, nh, gen, cov);
 }
 
 // k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile right of block column k (which needs

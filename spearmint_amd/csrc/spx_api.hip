@@ -386,21 +386,20 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     const int ps = (rl && !lazy && want_ps && h->lean_flow == 0) ? 1 : 0;   // (only without lean_flow, below)
     if (ps && (rc = h->ps_flags.reserve((size_t)nh * nblk * sizeof(int)))) return rc;   // zeroed by k_lean_rhs_init
     // The whole factorisation as ONE data-flow launch (k_lean_flow; option lean_flow, default on): against one launch per
-    // block column -20 % per call at N = 2048 (1-4 draws; -8 ... -13 % at 8-32), -10 % at N = 1000, -5 % at N = 256,
-    // level below (scripts/dev/flow_ab.py); the same factor bit for bit
+    // block column -27 ... -36 % per call at N = 2048 (1-32 draws), -25 ... -34 % at N = 1000, -20 % at N = 256, -6 ... -10 %
+    // at N = 64 (profiles/r03_flow_ab.log); the same factor bit for bit
     int* lflags = nullptr; int* dflags = nullptr; unsigned* tickets = nullptr;
     if (flow) {
-        const size_t nfl = (size_t)nh * (nblk + 1) * nblk + (size_t)nh * nblk + 1;
+        const size_t nfl = (size_t)nh * (nblk + 1) * nblk + (size_t)nh * nblk + 2;
         if (nfl > h->flow_flags_n || h->flow_gen >= (1 << 27)) {
             if ((rc = h->flow_flags.reserve(nfl * sizeof(int)))) return rc;
             HIPCHK(hipMemsetAsync(h->flow_flags.p, 0, h->flow_flags.cap, h->stream));
             h->flow_flags_n = h->flow_flags.cap / sizeof(int);
             h->flow_gen = 0;
-            h->flow_ticket_base = 0;
         }
         h->flow_gen += 1;
-        tickets = (unsigned*)h->flow_flags.p;          // first: its place does not move with the batch size
-        lflags = (int*)h->flow_flags.p + 1;
+        tickets = (unsigned*)h->flow_flags.p;          // first (counter, done count): their place does not move with the batch size
+        lflags = (int*)h->flow_flags.p + 2;
         dflags = lflags + (size_t)nh * (nblk + 1) * nblk;
     }
     h->flow_used = flow != 0;
@@ -425,7 +424,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     }
     h->factor_tiled = !lean && flow;
     if (flow)
-        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, lean ? h->diagL.d() : nullptr, lflags, dflags, tickets, &h->flow_ticket_base, Np, nh, h->flow_gen, flow_alone,
+        TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, lean ? h->diagL.d() : nullptr, lflags, dflags, tickets, Np, nh, h->flow_gen, flow_alone,
                                              cov_in_flow ? h->Xs.d() : nullptr, h->X2s.d(), h->s1.d(), h->htab.d(), (int)N, Dp, dev_kind(h)));
     for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {

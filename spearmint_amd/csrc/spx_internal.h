@@ -131,13 +131,12 @@ struct spx_handle {
     bool factor_tiled = false;                                      // the EI path's factor is tile-major (k_lean_flow made it)
     int lean_flow_cov = -1;                                         // option "lean_flow_cov": K(X,X) built inside k_lean_flow 1 / 0 / -1 = default (on)
     int lean_flow_cu = -1;                                          // option "lean_flow_cu": one workgroup per CU 1 / 0 / -1 = by size
-    DevBuf flow_flags;                                              // k_lean_flow: [H][nblk + 1][nblk] tile flags + [H][nblk] diagonal progress + the ticket counter
+    DevBuf flow_flags;                                              // k_lean_flow: [H][nblk + 1][nblk] tile flags + [H][nblk] diagonal progress + the ticket and done counters
     size_t flow_flags_n = 0;                                        // ints the flags were zeroed for
     int flow_gen = 0;                                               // generation of the last call (flags are compared, not cleared)
     PinBuf pin_up, pin_res;                                         // hyper-parameter upload staging; log-likelihood results
     bool handoff_timeout = false;                                   // finish_factor saw info < 0
     bool flow_used = false;                                         // the last factorisation ran k_lean_flow
-    unsigned flow_ticket_base = 0;                                  // tickets handed out by all earlier calls (the counter is never reset)
 
     double best_val = 0.0;
     int64_t best_idx = -1;
