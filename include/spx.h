@@ -233,7 +233,9 @@ const char* spx_timing_name(int i);
  *                   block column, in the forms selected by "lean_ps" / "lean_lazy";
  *   "ei_flow"       the same choice for spx_factor (default 1);
  *   "lean_flow_cu"  k_lean_flow with one workgroup per CU (1) or two (0); -1: by size;
- *   "lean_flow_cov" k_lean_flow builds the tiles of K(X,X) itself (1) or reads k_cov's (0); -1: by size;
+ *   "lean_flow_yield" with two per CU: a workgroup yields while its neighbour on the CU factors a
+ *                   diagonal block (1, default) or does not (0);
+ *   "lean_flow_cov" k_lean_flow builds the tiles of K(X,X) itself (1, default) or reads k_cov's (0);
  *   "lean_lazy"     trailing updates one (0) or two (1) block columns at a time;
  *   "lean_ps"       1: the panel solve of a block column runs inside the update launch, handed the
  *                   inverse of the diagonal block behind its pivots; 0: a launch of its own.

@@ -1,0 +1,26 @@
+"""Dev tool: the timeline of the diagonal items of k_lean_flow (library built with -DFLOW_STAMPS, scripts/dev/attic notes):
+per block column the wall-clock time its item started, finished its history, started and finished its diagonal block.
+   SPX_LIB=_variants/libspx_stamps.so python scripts/dev/flow_timeline.py H"""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from spearmint_amd.engine import Engine
+from spearmint_amd.synthetic import synthetic_problem
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+eng = Engine(0)
+comp, cand, vals, hyp = synthetic_problem(N, 16, 32, H, 5)
+eng.set_observations(comp, vals)
+for _ in range(5):
+    eng.set_hypers(hyp); eng.gp_logprob()
+buf = np.zeros(32 * 64 * 4, dtype=np.int64)
+eng._lib.spx_dev_flow_stamps(buf.ctypes.data_as(ctypes.c_void_p))
+st = buf.reshape(32, 64, 4)[:H, :N // 64].astype(float) / 100.0     # 100 MHz wall clock -> us
+t0 = st[:, 0, 0].min()
+st -= t0
+for h in (0, H - 1):
+    print("draw %d: column | item start | history done | diag start | diag end | diag time | gap to previous diag end" % h)
+    for c in range(N // 64):
+        s = st[h, c]
+        print("  %2d  %8.1f %8.1f %8.1f %8.1f   %6.1f   %6.1f" % (c, s[0], s[1], s[2], s[3], s[3] - s[2], s[2] - (st[h, c - 1, 3] if c else 0)))
+print("mean diag time %.2f us, mean gap %.2f us, total %.1f us" % ((st[:, :, 3] - st[:, :, 2]).mean(), np.mean(st[:, 1:, 2] - st[:, :-1, 3]), st[:, -1, 3].max()))

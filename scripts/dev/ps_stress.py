@@ -32,6 +32,7 @@ for c in range(ncfg):
     eng.set_option("lean_flow", 1 if form == "flow" else 0); eng.set_option("lean_ps", 1)
     eng.set_option("lean_flow_cu", int(rs.randint(-1, 2)))
     eng.set_option("lean_flow_cov", int(rs.randint(0, 2)))
+    eng.set_option("lean_flow_yield", int(rs.randint(0, 2)))
     for rep in range(6):
         eng.set_hypers(hyp); got = eng.gp_logprob(); calls += 1
         if not np.array_equal(got, ref, equal_nan=True):

@@ -912,13 +912,36 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
 
 // one history step of a chunk: a0 -= L_i,k L_lo,k^T, a1 -= L_i,k L_hi,k^T (DIAG: L_hi,k is L_i,k).  In: tA = L_i,k and
 // tB = L_lo,k (requested earlier); MORE: out, the same for step k + 1, requested during this step's products.
+// `busy` (two workgroups per CU): this CU's count of workgroups inside a diagonal block.  A diagonal block's dependent MFMA
+// chain runs a third slower beside a neighbour whose products keep the matrix pipes busy, and the whole call follows
+// that chain -- so a workgroup about to start a step's products while its neighbour factors a diagonal block waits for
+// it (14 us at most, on one CU per draw at a time; the word is read one step ahead, behind the products, so that
+// asking costs nothing).
+#define FLOW_YIELD_LIMIT 4096
+// (the other places where an item that is not a diagonal item starts a stretch of work: thread 0 waits, the others meet
+// it at the next barrier)
+__device__ __forceinline__ void flow_yield(const int* busy)
+{
+    if (busy && threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 && ++spins < FLOW_YIELD_LIMIT)
+            __builtin_amdgcn_s_sleep(16);
+    }
+}
 template <bool DIAG, bool MORE>
 __device__ __forceinline__ void flow_step(double* A, double* B, const double* pi, const double* pl, const double* ph,
-                                          d2 (&tA)[8], d2 (&tB)[8], d4 (&a0)[4], d4 (&a1)[4], int wave, int g, int li)
+                                          d2 (&tA)[8], d2 (&tB)[8], d4 (&a0)[4], d4 (&a1)[4], int wave, int g, int li,
+                                          const int* busy, int& busy_seen)
 {
+    if (busy && threadIdx.x == 0 && busy_seen > 0) {
+        int spins = 0;
+        while (__hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 && ++spins < FLOW_YIELD_LIMIT)
+            __builtin_amdgcn_s_sleep(16);
+    }
     planes_to_lds(tA, A, wave, g, li);
     planes_to_lds(tB, B, wave, g, li);
     __syncthreads();
+    if (busy && threadIdx.x == 0) busy_seen = __hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (MORE) load_tile_sc1_p(pi + LEAN_TILE, tA);
     if (!DIAG) load_tile_sc1_p(ph, tB);
     else if (MORE) load_tile_sc1_p(pl + LEAN_TILE, tB);
@@ -1015,13 +1038,14 @@ template <bool DIAG>
 __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, double* __restrict__ row, double* __restrict__ Lh,
                                            double* __restrict__ Dh, const int* lf, int* lf_row, int* df, int* info_h,
                                            double* __restrict__ diag_out, int i, int lo, int hi, int nblk, int gen,
-                                           const FlowCov& cov, int h, bool is_rhs)
+                                           const FlowCov& cov, int h, bool is_rhs, int* busy)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     const bool two = lo >= 0;
     __shared__ int s_n, s_val;
     d4 a0[4], a1[4], st[4];
+    if (!DIAG) { flow_yield(busy); __syncthreads(); }
     if (cov.Xs && !is_rhs) {
         if (two) flow_cov_tile(cov, h, nblk * NB, i, lo, a0);
         flow_cov_tile(cov, h, nblk * NB, i, hi, a1);
@@ -1036,6 +1060,7 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
     // k + 1 in flight during the products of step k: far behind the diagonal workgroups -- where most of the work is
     // -- a step costs its two products; next to them, one look and one round of loads instead of three of each.
     const int first = two ? lo : 0;
+    int busy_seen = 0;
 #pragma unroll 1
     for (int k = 0; k < first;) {
         if (wave == 0) {
@@ -1069,11 +1094,14 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
         load_tile_sc1_p(pl, tB);
 #pragma unroll 1
         for (int s = 0; s + 1 < n; ++s, pi += LEAN_TILE, pl += LEAN_TILE, ph += LEAN_TILE)
-            flow_step<DIAG, true>(A, B, pi, pl, ph, tA, tB, a0, a1, wave, g, li);
-        flow_step<DIAG, false>(A, B, pi, pl, ph, tA, tB, a0, a1, wave, g, li);
+            flow_step<DIAG, true>(A, B, pi, pl, ph, tA, tB, a0, a1, wave, g, li, busy, busy_seen);
+        flow_step<DIAG, false>(A, B, pi, pl, ph, tA, tB, a0, a1, wave, g, li, busy, busy_seen);
         k += n;
     }
     // ---- 2. tile (i, lo): always a panel tile (lo < hi <= i) ----
+    // (from here to the end of its diagonal block this item is the next link of the draw's chain: the neighbour yields)
+    if (DIAG && busy && threadIdx.x == 0) atomicAdd(busy, 1);
+    if (!DIAG) flow_yield(busy);
     if (two) {
         acc_tile_to_lds(a0, A, wave, g, li);
         flow_trsm<DIAG>(A, B, Dh + (size_t)lo * NB * NB, df + lo, gen, info_h, &s_val, st, row + (size_t)lo * LEAN_TILE, T16, a1, wave, g, li);
@@ -1093,12 +1121,14 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
         if (threadIdx.x == 0) __hip_atomic_store(lf_row + lo, 8 * gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and says so
     }
     // ---- 3. tile (i, hi) ----
+    if (!DIAG) flow_yield(busy);
     acc_tile_to_lds(a1, A, wave, g, li);
     __syncthreads();
     if (DIAG) {
         // (the EI path keeps L_ii -- row-major in its tile's place -- for spx_get_factor; the log-likelihood path only its diagonal)
         diag_block<true>(A, B, T16, info_h, i * NB, diag_out ? nullptr : row + (size_t)i * LEAN_TILE, NB, Dh + (size_t)i * NB * NB, diag_out,
                          df + i, 8 * gen);
+        if (busy && threadIdx.x == 0) atomicAdd(busy, -1);
     } else {
         flow_trsm<false>(A, B, Dh + (size_t)hi * NB * NB, df + hi, gen, info_h, &s_val, st, row + (size_t)hi * LEAN_TILE, T16, a1, wave, g, li);
         drain_stores();
@@ -1111,7 +1141,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
                                                    int* __restrict__ info, double* __restrict__ rhs,
                                                    double* __restrict__ diagL, int* __restrict__ lflags,
                                                    int* __restrict__ dflags, unsigned* __restrict__ tickets,
-                                                   int Np, int nh, int gen, FlowCov cov)
+                                                   int Np, int nh, int gen, FlowCov cov, int* __restrict__ cu_busy)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;              // [64][LDP]
@@ -1154,11 +1184,18 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     int* df = dflags + (size_t)h * nblk;
     double* Dh = Dinv + (size_t)h * nblk * NB * NB;
 
+    // this CU's word of cu_busy (null: one workgroup per CU, nobody to yield to): XCC_ID[3:0] and HW_ID[15:8] = SE, SH, CU
+    int* busy = nullptr;
+    if (cu_busy) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        const unsigned cu = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);
+        busy = cu_busy + ((xcc & 15u) << 8 | (cu & 255u));
+    }
     const bool diag = !is_rhs && hi == i;
     // the two kinds of chunk as two straight-line bodies (one body with the distinction inside costs the register
     // allocator 110 registers more than either)
-    if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL ? diagL + (size_t)h * Np + (size_t)i * NB : nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs);
-    else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs);
+    if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL ? diagL + (size_t)h * Np + (size_t)i * NB : nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs, busy);
+    else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs, busy);
     if (threadIdx.x == 0 && atomicAdd(tickets + 1, 1u) == gridDim.x - 1) {   // everybody else has left (and long since drawn a ticket)
         __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1167,7 +1204,8 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
 
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
                       int* dflags, unsigned* tickets, int Np, int nh, int gen, bool alone,
-                      const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind)
+                      const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind,
+                      int* cu_busy)
 {
     FlowCov cov{Xs, X2s, s1, htab, N, Dp, kind};
     const int nblk = Np / NB;
@@ -1181,7 +1219,7 @@ void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double
     if (alone) lds = 96 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_lean_flow, dim3(nh * ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, tickets,
-                       Np, nh, gen, cov);
+                       Np, nh, gen, cov, alone ? nullptr : cu_busy);
 }
 
 // k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile right of block column k (which needs

@@ -57,7 +57,8 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
                          int Np, int k, int nh);
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
                       int* dflags, unsigned* tickets, int Np, int nh, int gen, bool alone,
-                      const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind);
+                      const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind,
+                      int* cu_busy);
 void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh,
                           int* info, int* flags);
 void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int* info_out,

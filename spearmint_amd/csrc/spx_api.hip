@@ -184,6 +184,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_flow_cov = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
+    if (!strcmp(name, "lean_flow_yield")) {   // k_lean_flow, two workgroups per CU: yield to a neighbour's diagonal block (1, default) or not (0)
+        h->lean_flow_yield = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
     if (!strcmp(name, "lean_flow_cu")) {   // k_lean_flow: one workgroup per CU (1), two (0), by size (-1, default)
         h->lean_flow_cu = value < 0 ? -1 : (value != 0);
         return SPX_OK;
@@ -367,11 +371,10 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     const bool tiled = rl || flow;
     // (how busy the launch will be: draws x block columns^1.5 -- the two rules below were read off scripts/dev/lib_ab.py)
     const double flow_load = (double)nh * nblk * sqrt((double)nblk);
-    const bool flow_alone = h->lean_flow_cu >= 0 ? h->lean_flow_cu != 0 : flow_load <= 1500.0;
-    // In the launch: -4 ... -10 % per call (N = 2048: 1-2 draws and from 12; N <= 1000; no k_cov launch, no round trip of
-    // the matrix through memory), except where every workgroup has a CU to itself and the CUs are about to run out
-    // (N = 2048: 6-8 draws, +2 ... +4 %): there the covariance stays a launch of its own.
-    const bool cov_in_flow = flow && (h->lean_flow_cov >= 0 ? h->lean_flow_cov != 0 : !(flow_alone && flow_load > 1000.0));
+    const bool flow_alone = h->lean_flow_cu >= 0 ? h->lean_flow_cu != 0 : flow_load <= 800.0;
+    // In the launch: -1 ... -8 % per call at every size (no k_cov launch, no round trip of the matrix through memory;
+    // scripts/dev/lean_option_ab.py lean_flow_cov)
+    const bool cov_in_flow = flow && h->lean_flow_cov != 0;
     if (!cov_in_flow)
         TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, tiled, dev_kind(h)));
     // Trailing updates two block columns at a time (k_lean_step2) halve the traffic of the trailing matrices but
@@ -388,9 +391,9 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // The whole factorisation as ONE data-flow launch (k_lean_flow; option lean_flow, default on): against one launch per
     // block column -27 ... -36 % per call at N = 2048 (1-32 draws), -25 ... -34 % at N = 1000, -20 % at N = 256, -6 ... -10 %
     // at N = 64 (profiles/r03_flow_ab.log); the same factor bit for bit
-    int* lflags = nullptr; int* dflags = nullptr; unsigned* tickets = nullptr;
+    int* lflags = nullptr; int* dflags = nullptr; int* cu_busy = nullptr; unsigned* tickets = nullptr;
     if (flow) {
-        const size_t nfl = (size_t)nh * (nblk + 1) * nblk + (size_t)nh * nblk + 2;
+        const size_t nfl = (size_t)nh * (nblk + 1) * nblk + (size_t)nh * nblk + 2 + 4096;   // (+ one word per CU: cu_busy)
         if (nfl > h->flow_flags_n || h->flow_gen >= (1 << 27)) {
             if ((rc = h->flow_flags.reserve(nfl * sizeof(int)))) return rc;
             HIPCHK(hipMemsetAsync(h->flow_flags.p, 0, h->flow_flags.cap, h->stream));
@@ -399,14 +402,18 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         }
         h->flow_gen += 1;
         tickets = (unsigned*)h->flow_flags.p;          // first (counter, done count): their place does not move with the batch size
-        lflags = (int*)h->flow_flags.p + 2;
+        cu_busy = (int*)h->flow_flags.p + 2;           // [xcc][se, sh, cu]: workgroups inside a diagonal block, back to 0 after every launch
+        lflags = cu_busy + 4096;
         dflags = lflags + (size_t)nh * (nblk + 1) * nblk;
     }
     h->flow_used = flow != 0;
-    // One workgroup per CU while the call is bound by the chain of diagonal blocks rather than by the products (option
-    // lean_flow_cu: 1 / 0 / -1 = by size).  Measured (scripts/dev/lib_ab.py), alone against shared: N = 2048: -7 % at 2
-    // draws, -14 % at 4, -9 % at 6, -3 % at 8, +16 % at 12; N = 1000: -4 ... -12 % up to 12 draws, +6 % at 32; N = 4096:
-    // -10 % / -5 % at 1 / 2 draws, +12 % at 4; N = 512: level, -10 % from 20 draws.  The rule above separates the two sides.
+    // Residency (option lean_flow_cu: 1 / 0 / -1 = by size; scripts/dev/flow_modes.py).  A diagonal block's dependent MFMA
+    // chain runs a third slower beside a neighbour whose products keep the matrix pipes busy, and the whole call follows
+    // that chain.  Small launches (draws x block columns^1.5 <= 800: N = 2048 up to 4 draws, N = 1000 up to 12) get ONE
+    // workgroup per CU (the launch asks for 96 KB of LDS).  Larger ones need the places: two per CU, and a workgroup yields
+    // while its neighbour is the next link of a draw's chain -- from the end of its history through its diagonal block
+    // (option lean_flow_yield; a word per CU, found by XCC_ID / HW_ID).  Against two per CU without yielding: N = 2048:
+    // -11 % at 4 draws, -13 % at 6, -10 % at 8, -2 % at 12; N = 4096: -16 % at 2 draws; N = 1000: -7 % at 20 draws.
     // lean: the right-hand side vals - mean rides through the factorisation as an extra row block,
     // so y = L^-1 (vals - mean) is ready when the last column is
     double* rhs = nullptr;
@@ -425,7 +432,8 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     h->factor_tiled = !lean && flow;
     if (flow)
         TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, lean ? h->diagL.d() : nullptr, lflags, dflags, tickets, Np, nh, h->flow_gen, flow_alone,
-                                             cov_in_flow ? h->Xs.d() : nullptr, h->X2s.d(), h->s1.d(), h->htab.d(), (int)N, Dp, dev_kind(h)));
+                                             cov_in_flow ? h->Xs.d() : nullptr, h->X2s.d(), h->s1.d(), h->htab.d(), (int)N, Dp, dev_kind(h),
+                                             h->lean_flow_yield != 0 ? cu_busy : nullptr));
     for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {
             TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));

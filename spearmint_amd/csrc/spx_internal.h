@@ -130,6 +130,7 @@ struct spx_handle {
     int ei_flow = -1;                                               // option "ei_flow": spx_factor through k_lean_flow 1 / 0 / -1 = default (on)
     bool factor_tiled = false;                                      // the EI path's factor is tile-major (k_lean_flow made it)
     int lean_flow_cov = -1;                                         // option "lean_flow_cov": K(X,X) built inside k_lean_flow 1 / 0 / -1 = default (on)
+    int lean_flow_yield = -1;                                       // option "lean_flow_yield": 1 / 0 / -1 = default (on)
     int lean_flow_cu = -1;                                          // option "lean_flow_cu": one workgroup per CU 1 / 0 / -1 = by size
     DevBuf flow_flags;                                              // k_lean_flow: [H][nblk + 1][nblk] tile flags + [H][nblk] diagonal progress + the ticket and done counters
     size_t flow_flags_n = 0;                                        // ints the flags were zeroed for

@@ -344,10 +344,12 @@ def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
     try:
         # (cu: one workgroup per CU or two, by default chosen from the size; cov: K(X,X) built tile by tile inside the
         # launch, the default, or by k_cov before it)
-        for flow, cu, cov in ((1, 1, 1), (1, 0, 1), (1, -1, 0), (0, -1, -1)):
+        # ... yl: with two per CU, a workgroup yields while its neighbour factors a diagonal block, or does not)
+        for flow, cu, cov, yl in ((1, 1, 1, -1), (1, 0, 1, 1), (1, 0, 1, 0), (1, -1, 0, -1), (0, -1, -1, -1)):
             eng.set_option("lean_flow", flow)
             eng.set_option("lean_flow_cu", cu)
             eng.set_option("lean_flow_cov", cov)
+            eng.set_option("lean_flow_yield", yl)
             for lo, hi in ((0, 1), (1, 6), (6, 38), (20, 40)):
                 eng.set_hypers(hypers[lo:hi])
                 assert np.array_equal(eng.gp_logprob(), big[lo:hi])
@@ -374,6 +376,7 @@ def test_gpu_loglikelihood_batch_size_does_not_change_bits(eng):
         eng.set_option("lean_flow", -1)
         eng.set_option("lean_flow_cu", -1)
         eng.set_option("lean_flow_cov", -1)
+        eng.set_option("lean_flow_yield", -1)
 
 
 def _lean_form(eng, form):
