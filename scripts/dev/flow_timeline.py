@@ -1,4 +1,4 @@
-"""Dev tool: the timeline of the diagonal items of k_lean_flow (library built with -DFLOW_STAMPS, scripts/dev/attic notes):
+"""Dev tool: the timeline of the diagonal items of k_lean_flow (a library built with FLOW_STAMPS=1, see csrc/Makefile):
 per block column the wall-clock time its item started, finished its history, started and finished its diagonal block.
    SPX_LIB=_variants/libspx_stamps.so python scripts/dev/flow_timeline.py H"""
 import os, sys, ctypes

@@ -766,6 +766,14 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 // size and the matrix size change between calls and with them which word is which flag -- whatever an earlier call
 // left anywhere is below 8 gen.
 #define FLOW_SPIN_LIMIT (1 << 20)
+#ifdef FLOW_STAMPS   // dev (make FLOW_STAMPS=1; scripts/dev/flow_timeline.py): wall-clock stamps of every diagonal item,
+                     // [draw][column][4] = item start, history done, diagonal block start, diagonal block end
+__device__ long long g_flow_stamps[32 * 64 * 4];
+extern "C" void spx_dev_flow_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_stamps), sizeof(g_flow_stamps)); }
+#define FSTAMP(h, c, j) do { if (threadIdx.x == 0 && (h) < 32) g_flow_stamps[((h) * 64 + (c)) * 4 + (j)] = wall_clock64(); } while (0)
+#else
+#define FSTAMP(h, c, j)
+#endif
 #define FLOW_BATCH 8        // history steps looked at per poll (3 flags each: 24 lanes)
 
 // a tile past the non-coherent caches (sc1: device scope), 16 bytes per lane and access like load_tile / store_tile
@@ -1045,6 +1053,7 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
     const bool two = lo >= 0;
     __shared__ int s_n, s_val;
     d4 a0[4], a1[4], st[4];
+    if (DIAG) FSTAMP(h, i, 0);
     if (!DIAG) { flow_yield(busy); __syncthreads(); }
     if (cov.Xs && !is_rhs) {
         if (two) flow_cov_tile(cov, h, nblk * NB, i, lo, a0);
@@ -1100,6 +1109,7 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
     }
     // ---- 2. tile (i, lo): always a panel tile (lo < hi <= i) ----
     // (from here to the end of its diagonal block this item is the next link of the draw's chain: the neighbour yields)
+    if (DIAG) FSTAMP(h, i, 1);
     if (DIAG && busy && threadIdx.x == 0) atomicAdd(busy, 1);
     if (!DIAG) flow_yield(busy);
     if (two) {
@@ -1124,11 +1134,13 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
     if (!DIAG) flow_yield(busy);
     acc_tile_to_lds(a1, A, wave, g, li);
     __syncthreads();
+    if (DIAG) FSTAMP(h, i, 2);
     if (DIAG) {
         // (the EI path keeps L_ii -- row-major in its tile's place -- for spx_get_factor; the log-likelihood path only its diagonal)
         diag_block<true>(A, B, T16, info_h, i * NB, diag_out ? nullptr : row + (size_t)i * LEAN_TILE, NB, Dh + (size_t)i * NB * NB, diag_out,
                          df + i, 8 * gen);
         if (busy && threadIdx.x == 0) atomicAdd(busy, -1);
+        FSTAMP(h, i, 3);
     } else {
         flow_trsm<false>(A, B, Dh + (size_t)hi * NB * NB, df + hi, gen, info_h, &s_val, st, row + (size_t)hi * LEAN_TILE, T16, a1, wave, g, li);
         drain_stores();
