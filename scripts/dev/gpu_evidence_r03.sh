@@ -8,6 +8,7 @@ echo "== bench c2"; timeout 300 python bench.py --workload c2 --skip-extras > $O
 echo "== bench c5"; timeout 300 python bench.py --workload c5 --skip-extras > $O/r03_c5_bench_line.json 2>> $O/bench_c5.err
 echo "== time_lean"; timeout 300 python scripts/time_lean.py > $O/r03_time_lean.log 2>&1; cat $O/r03_time_lean.log
 echo "== flow A/B"; timeout 300 python scripts/dev/flow_ab.py 2>&1 | grep -v Warn > $O/r03_flow_ab.log; head -8 $O/r03_flow_ab.log
+echo "== flow modes"; timeout 300 python scripts/dev/flow_modes.py > $O/r03_flow_modes.log 2>&1; head -8 $O/r03_flow_modes.log
 echo "== stress"; (timeout 200 python scripts/dev/ps_stress.py 600 flow; timeout 200 python scripts/dev/ps_stress.py 300 ps) 2>&1 | tail -2 > $O/r03_flow_stress.log; cat $O/r03_flow_stress.log
 echo "== next()"; timeout 300 python scripts/profile_next.py 2048 200000 32 "" "mcmc_iters=20,grid_subset=20" 2>&1 | head -14 > $O/r03_next_profile.log
 timeout 300 python scripts/dev/next_hist.py 2>&1 | tail -4 >> $O/r03_next_profile.log; cat $O/r03_next_profile.log
