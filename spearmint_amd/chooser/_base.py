@@ -70,9 +70,11 @@ class GPEIBase(object):
         # costs 0.067 ms up to N = 128 whether it carries one hyper row or six (one launch for the factorisation, results
         # written into pinned host memory), a host evaluation 0.022 ms at N = 8, 0.030 at 32, 0.049 at 64, 0.081 at 96, 0.22
         # at 128; a slice move needs ~4.4 evaluations one after the other on the host or ~1.3 speculative batches on the GPU:
-        # break-even near N = 10, "auto" switches at 32.  (N = 2048: 0.59 ms per GPU call vs 250 ms.)
+        # break-even near N = 10, "auto" switches at 16.  (N = 2048: 0.58 ms per GPU call vs 250 ms.)
         self.gpu_logprob = str(gpu_logprob)
-        # same choice for the EI + gradient objective of the local refinement (spx_ei_grad)
+        # same choice for the EI + gradient objective of the local refinement (spx_ei_grad_batch).  There the GPU wins at
+        # every size (scripts/dev/refine_threshold.py, 10 draws: one call for all 20 refinement points 0.06 ms from N = 8 to
+        # N = 128; the host's per-draw models 0.74 ms per POINT at N = 8, 0.96 at 128): "auto" = GPU.
         self.gpu_refine = str(gpu_refine)
         self.lookahead = max(1, int(lookahead))   # slice-sampler proposals evaluated speculatively per GPU call
         # opt-in: have the driver's ExperimentGrid build its Sobol candidate grid with the HIP
@@ -151,12 +153,12 @@ class GPEIBase(object):
     # -- log-likelihood data term: host or GPU ------------------------------------------
     def _use_gpu_logprob(self, n):
         if self.gpu_logprob == "auto":
-            return n >= 32
+            return n >= 16
         return _as_bool(self.gpu_logprob)
 
     def _use_gpu_refine(self, n):
         if self.gpu_refine == "auto":
-            return n >= 64
+            return True
         return _as_bool(self.gpu_refine)
 
     def data_logprob(self, comp, vals, mean, amp2, noise, ls):

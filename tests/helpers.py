@@ -39,6 +39,17 @@ class OracleEngine(object):
     def factor(self):
         self.chols = [orc.posterior(self.comp, self.vals, h)[1] for h in self.hypers]
 
+    def gp_logprob(self):
+        """The sampler's data term for every resident hyper row [mean, noise, amp2, ls...] (-inf where the covariance
+        is not positive definite), from the oracle's restatement of GPEIChooser.py:281-285."""
+        out = np.empty(self.hypers.shape[0])
+        for k, h in enumerate(self.hypers):
+            try:
+                out[k] = orc.gp_logprob(self.comp, self.vals, h[0], h[2], h[1], h[3:])
+            except np.linalg.LinAlgError:
+                out[k] = -np.inf
+        return out
+
     def get_factor(self, draw, want_K=True, want_L=True, want_alpha=True):
         return None, self.chols[draw], None
 
@@ -120,7 +131,7 @@ def _under_covar(fn):
     return wrapped
 
 
-for _name in ("get_time_mean", "factor", "ei_run", "ei_grid", "ei_grad_batch", "ei_per_sec_grid"):
+for _name in ("get_time_mean", "factor", "gp_logprob", "ei_run", "ei_grid", "ei_grad_batch", "ei_per_sec_grid"):
     setattr(OracleEngine, _name, _under_covar(getattr(OracleEngine, _name)))
 
 
