@@ -354,26 +354,26 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     const double* ls = h->hyp.d() + 3;
     // x / ls and, in the same launch, the second operand pre-multiplied by 2 (gp.py:50; exact)
     TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d(), h->X2s.d()));
-    // Blocked left-looking Cholesky for the EI path (many draws: every panel launch fills the chip).
-    // The log-likelihood path (a handful of draws) runs the same 64x64 tiles right-looking, on a
-    // tile-major copy of the matrix: one-step-deep launches instead of k sequential steps per tile, the
-    // diagonal block factored inside the update launch (k_lean_step); same accumulation order, same bits.
+    // The factorisation, blocked with 64x64 tiles; three generations, the same factor bit for bit (every tile receives its
+    // update steps in the order 0, 1, 2, ..., through the same MFMA chains, and the diagonal blocks share diag_block):
+    //   flow  k_lean_flow: ONE data-flow launch for all block columns of all draws, tile-major storage (the default);
+    //   rl    the log-likelihood path's one-step-deep launches per block column, tile-major (k_lean_step_ps, or
+    //         k_lean_step [+ k_lean_step2] + k_lean_trsm), up to 32 draws -- the fallback of `flow` there;
+    //   else  the batched left-looking launches of the EI path, row-major (k_chol_diag + k_chol_panel) -- the fallback of
+    //         `flow` for spx_factor, and the log-likelihood path beyond 32 draws.
     const int rl = (lean && nh <= 32) ? 1 : 0;   // beyond ~40 draws the one-step launches are work-bound and lose
-    // k_lean_flow builds the tiles of K(X,X) itself, where they are consumed (option lean_flow_cov = 0: k_cov does, as for
-    // every other path)
-    // The EI path (spx_factor) takes the same launch (option ei_flow, default on; measured against the left-looking
+    // The EI path (spx_factor) takes the data-flow launch too (option ei_flow, default on; measured against the left-looking
     // launches: factor stage 0.28 -> 0.19 ms at N = 256 x 10 draws, 6.3 -> 3.8 ms at 2048 x 20, 2.3 -> 1.5 ms at
-    // 1024 x 40, 0.85 -> 0.61 ms at 512 x 60): no right-hand-side rows, the diagonal blocks of L kept for spx_get_factor, W = L^-1 from the
-    // tile-major factor (k_trinv<true>).  The same factor bit for bit (per-tile update order and diagonal blocks are
-    // shared with the left-looking kernels), so every EI result stays what it was.
+    // 1024 x 40, 0.85 -> 0.61 ms at 512 x 60): no right-hand-side rows, the diagonal blocks of L kept for spx_get_factor,
+    // W = L^-1 from the tile-major factor (k_trinv<true>); every EI result stays what it was.
     const int eflow = (!lean && h->ei_flow != 0) ? 1 : 0;
     const int flow = ((rl || eflow) && h->lean_flow != 0) ? 1 : 0;
     const bool tiled = rl || flow;
-    // (how busy the launch will be: draws x block columns^1.5 -- the two rules below were read off scripts/dev/lib_ab.py)
+    // (how busy the launch will be: draws x block columns^1.5 -- the residency rule below was read off scripts/dev/flow_modes.py)
     const double flow_load = (double)nh * nblk * sqrt((double)nblk);
     const bool flow_alone = h->lean_flow_cu >= 0 ? h->lean_flow_cu != 0 : flow_load <= 800.0;
-    // In the launch: -1 ... -8 % per call at every size (no k_cov launch, no round trip of the matrix through memory;
-    // scripts/dev/lean_option_ab.py lean_flow_cov)
+    // k_lean_flow builds the tiles of K(X,X) itself, where they are consumed: -1 ... -8 % per call at every size (no k_cov
+    // launch, no round trip of the matrix through memory; option lean_flow_cov, scripts/dev/lean_option_ab.py)
     const bool cov_in_flow = flow && h->lean_flow_cov != 0;
     if (!cov_in_flow)
         TIMED(ST_COV_SELF, launch_cov_self(s, h->Xs.d(), h->s1.d(), h->X2s.d(), h->htab.d(), h->Lm.d(), (int)N, Np, Dp, nh, tiled, dev_kind(h)));
