@@ -741,7 +741,8 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 }
 
 // ---------------------------------------------------------------------------
-// k_lean_flow: the WHOLE factorisation of the log-likelihood path in ONE launch, as a data-flow program.
+// k_lean_flow: the WHOLE factorisation -- of the log-likelihood path (spx_gp_logprob, with the right-hand-side rows) and
+// of the EI path (spx_factor, without) -- in ONE launch, as a data-flow program.
 //
 // Every dependency of the blocked factorisation -- diagonal block -> panel tile -> update -> next diagonal block --
 // is a hand-off inside the launch (the mechanism k_lean_step_ps proved: write-through stores, drained, a flag;
@@ -749,6 +750,7 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 // A workgroup owns two neighbouring tiles (i, hi-1), (i, hi) of a block row (chunks are aligned to the RIGHT end of
 // the row, so that the tile next to the diagonal and the diagonal tile always share a workgroup) and processes them
 // LEFT-looking, accumulators in registers:
+//   0. the tiles of K(X,X) + noise are built where they are consumed (flow_cov_tile; or loaded, if k_cov ran);
 //   1. history: for k < hi-1 both tiles take step k as soon as L_ik, L_hi-1,k and L_hi,k are published;
 //   2. tile (i, hi-1): the diagonal block (if it is the diagonal tile) or its panel solve, block column by block
 //      column behind the pivots of the diagonal workgroup of that column, then PUBLISHED (tile + flag);
@@ -765,6 +767,9 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 // published; Dflag[h][col] = 8 gen + b once block rows 0 .. b-1 of Dinv_col are.  One scale for both kinds: the batch
 // size and the matrix size change between calls and with them which word is which flag -- whatever an earlier call
 // left anywhere is below 8 gen.
+// The call follows the chain of diagonal blocks, and a diagonal block runs a third slower beside a neighbour on its
+// CU whose products keep the matrix pipes busy: small launches ask for so much LDS that every workgroup has a CU to
+// itself; in large ones a workgroup yields while its neighbour is the next link of a chain (flow_step, cu_busy).
 #define FLOW_SPIN_LIMIT (1 << 20)
 #ifdef FLOW_STAMPS   // dev (make FLOW_STAMPS=1; scripts/dev/flow_timeline.py): wall-clock stamps of every diagonal item,
                      // [draw][column][4] = item start, history done, diagonal block start, diagonal block end
