@@ -91,12 +91,51 @@ def slice_sample(init_x, logprob, sigma=1.0, step_out=True, max_steps_out=1000, 
 # rejected shrink proposal moves the bracket by the SIGN of the proposal only.
 # So a batch of the next few points can be evaluated in one call (on the GPU a
 # batch of factorisations costs the latency of one) and then consumed in the
-# reference's order.  Random numbers are drawn speculatively and the global
-# numpy RNG is rewound to exactly the state the reference would have reached
+# reference's order.  Random numbers are drawn ahead of their use (_Uniforms) and the
+# global numpy RNG is left in exactly the state the reference would have reached
 # (util.py:40-57: one rand() per shrink proposal), so a seeded run is bit-for-bit
 # the same Markov chain.
 # ---------------------------------------------------------------------------
-def _slice_along_batched(direction, x0, logprob_many, sigma, step_out, max_steps_out, lookahead, dim=None):
+class _Uniforms(object):
+    """The stream of npr.rand() with look-ahead.  peek(n) shows the next n numbers without consuming them, take()
+    consumes one; close() leaves the global generator exactly where as many plain npr.rand() calls as were taken
+    would have left it.  One state copy per slice_sample_batched call instead of four per move (get_state /
+    set_state copy the 2.5 KB Mersenne-Twister state: 20-45 us each, which was most of a move's host time)."""
+
+    def __init__(self):
+        self.state0 = npr.get_state()
+        self.buf = []        # drawn from the generator, not yet taken
+        self.taken = 0
+
+    def peek(self, n):
+        while len(self.buf) < n:
+            self.buf.append(npr.rand())
+        return self.buf[:n]
+
+    def take(self):
+        self.taken += 1
+        return self.buf.pop(0) if self.buf else npr.rand()
+
+    def close(self):
+        if self.buf:         # the generator is ahead of the consumer: back to the start, forward by what was taken
+            npr.set_state(self.state0)
+            for _ in range(self.taken):
+                npr.rand()
+            self.buf = []
+
+
+def _slice_along_batched(direction, x0, logprob_many, sigma, step_out, max_steps_out, lookahead, dim=None, rng=None):
+    own_rng = rng is None
+    if own_rng:
+        rng = _Uniforms()
+    try:
+        return _slice_along_batched_impl(direction, x0, logprob_many, sigma, step_out, max_steps_out, lookahead, dim, rng)
+    finally:
+        if own_rng:
+            rng.close()
+
+
+def _slice_along_batched_impl(direction, x0, logprob_many, sigma, step_out, max_steps_out, lookahead, dim, rng):
     def many(zs):
         return logprob_many([direction * z + x0 for z in zs])
 
@@ -109,9 +148,9 @@ def _slice_along_batched(direction, x0, logprob_many, sigma, step_out, max_steps
     adm = getattr(logprob_many, "admissible", None)
     hist = getattr(logprob_many, "history", None)
 
-    hi = sigma * npr.rand()
+    hi = sigma * rng.take()
     lo = hi - sigma
-    u_level = npr.rand()
+    u_level = rng.take()
     # f(0), f(lo), f(hi) are always evaluated by the reference; add the next step-outs
     # speculatively.  Positions are generated by repeated addition, exactly like the
     # reference's `lower -= sigma` / `upper += sigma`, so they round identically.
@@ -178,9 +217,7 @@ def _slice_along_batched(direction, x0, logprob_many, sigma, step_out, max_steps
         counts = [lookahead - max(1, lookahead // 3), max(1, lookahead // 3)]
     else:
         counts = [lookahead - lookahead // 2, lookahead // 2]
-    state0 = npr.get_state()
-    us = [npr.rand() for _ in range(max(counts))]
-    npr.set_state(state0)
+    us = rng.peek(max(counts))
     spec = []                # (bracket, offset into zs, number of uniforms, number of proposals)
     for br, cnt in zip(scen, counts):
         zl = propose(br[0], br[1], us[:cnt])
@@ -220,35 +257,26 @@ def _slice_along_batched(direction, x0, logprob_many, sigma, step_out, max_steps
         if (lo, hi) == br:
             hit = (at, nu, cnt)      # the speculated proposals for this bracket are the real ones
     while True:
-        state = npr.get_state()
         if hit is not None:
             base, nu, cnt = hit
-            zlist = propose(lo, hi, [npr.rand() for _ in range(nu)])     # same RNG state, same bracket: already evaluated
+            zlist = propose(lo, hi, rng.peek(nu))     # same numbers, same bracket: already evaluated
             batch = vals
             hit = None
         else:
-            zlist = propose(lo, hi, [npr.rand() for _ in range(lookahead)])
+            zlist = propose(lo, hi, rng.peek(lookahead))
             batch, base = many(zlist), 0
         for k, z in enumerate(zlist):
+            rng.take()                          # the reference draws one number per proposal it reaches (util.py:40-57)
             lp = batch.get(base + k)
             if np.isnan(lp):
-                npr.set_state(state)
-                for _ in range(k + 1):
-                    npr.rand()
                 raise SliceSamplerError("Slice sampler got a NaN")
             if lp > level:
-                npr.set_state(state)        # rewind: the reference consumed k+1 numbers
-                for _ in range(k + 1):
-                    npr.rand()
                 return z * direction + x0
             if z < 0:
                 lo = z
             elif z > 0:
                 hi = z
             else:
-                npr.set_state(state)
-                for _ in range(k + 1):
-                    npr.rand()
                 raise SliceSamplerError("Slice sampler shrank to zero!")
         # every proposal of this batch rejected and consumed; continue with the shrunk bracket
 
@@ -280,10 +308,14 @@ def slice_sample_batched(init_x, logprob_many, sigma=1.0, step_out=True, max_ste
         order = list(range(dims))
         npr.shuffle(order)
         cur = x.copy()
-        for d in order:
-            e = np.zeros(dims)
-            e[d] = 1.0
-            cur = _slice_along_batched(e, cur, logprob_many, sigma, step_out, max_steps_out, lookahead, dim=d)
+        rng = _Uniforms()        # (after the shuffle: from here on every draw of the moves is a plain rand())
+        try:
+            for d in order:
+                e = np.zeros(dims)
+                e[d] = 1.0
+                cur = _slice_along_batched(e, cur, logprob_many, sigma, step_out, max_steps_out, lookahead, dim=d, rng=rng)
+        finally:
+            rng.close()
         return cur
     direction = npr.randn(dims)
     direction = direction / np.sqrt(np.sum(direction ** 2))
