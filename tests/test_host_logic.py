@@ -571,3 +571,61 @@ def test_host_code_parses_with_the_python2_grammar():
     assert len(files) > 10
     for f in files:
         drv.parse_string(open(f).read() + "\n")
+
+
+def test_uniform_stream_lookahead_leaves_the_generator_where_plain_draws_would():
+    """util._Uniforms: peek() shows numbers ahead of their use, take() consumes them in order, close() leaves numpy's
+    global generator exactly where as many plain npr.rand() calls as were taken would have left it -- with numbers
+    peeked but never taken, with more taken than ever peeked, and with nothing peeked at all."""
+    for peeks, takes in [((4, 2), 3), ((6,), 9), ((), 5), ((3, 8), 0), ((2,), 2)]:
+        npr.seed(123)
+        plain = [npr.rand() for _ in range(takes)]
+        want = npr.get_state()
+        npr.seed(123)
+        u = util._Uniforms()
+        seen = []
+        for n in peeks:
+            seen = u.peek(n)
+            assert len(seen) == n
+        got = [u.take() for _ in range(takes)]
+        u.close()
+        have = npr.get_state()
+        assert got == plain
+        assert list(seen[:takes]) == plain[:min(takes, len(seen))][:len(seen)]
+        assert np.array_equal(want[1], have[1]) and want[2] == have[2]
+
+
+def test_batched_row_builder_equals_the_per_point_one(tmp_path):
+    """chooser._speculative_logprob with `to_rows` (the hyper rows and a-priori rejections of a whole speculative batch in
+    a few array operations) gives the sampler exactly what the per-point `to_row` path gives: same values, same -inf
+    entries, same memo behaviour -- checked through the length-scale sampler's adapter on the stand-in engine."""
+    from spearmint_amd.chooser import GPEIChooser
+    from tests.helpers import OracleEngine
+    rs = np.random.RandomState(3)
+    comp = rs.rand(30, 3); vals = rs.randn(30)
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=2,gpu_logprob=1")
+    ch._eng = OracleEngine()
+    max_ls = 2.0
+    mean, noise, amp2 = 0.1, 1e-3, 1.2
+
+    def inside(x):
+        return not ((x < 0).any() or (x > max_ls).any())
+
+    def to_row(x):
+        return np.concatenate(([mean, noise, amp2], x)) if inside(x) else None
+
+    def to_rows(X):
+        ok = ~((X < 0) | (X > max_ls)).any(axis=1)
+        R = np.empty((X.shape[0], 3 + X.shape[1]))
+        R[:, 0] = mean; R[:, 1] = noise; R[:, 2] = amp2; R[:, 3:] = X
+        return [R[k] if ok[k] else None for k in range(X.shape[0])]
+    xs = [rs.rand(3) * 1.5 for _ in range(5)] + [np.array([0.5, -0.1, 1.0]), np.array([0.5, 2.5, 1.0])]
+    a = ch._speculative_logprob(comp, vals, to_row, lambda x, lp: lp, admissible=inside)
+    b = ch._speculative_logprob(comp, vals, to_row, lambda x, lp: lp, admissible=inside, to_rows=to_rows)
+    for batch in (xs, xs[2:6] + xs[:1], xs[5:7], xs[:1]):
+        va, vb = a(batch), b(batch)
+        assert len(va.values) == len(vb.values)
+        for k in range(len(batch)):
+            assert (va.errors[k] is None) == (vb.errors[k] is None)
+            assert va.values[k] == vb.values[k] or (np.isnan(va.values[k]) and np.isnan(vb.values[k]))
+        assert [np.isneginf(v) for v in va.values] == [np.isneginf(v) for v in vb.values]
