@@ -8,7 +8,7 @@ from spearmint_amd.synthetic import synthetic_problem
 MODES = (("rule", -1, -1), ("2/CU+yield", 0, 1), ("2/CU", 0, 0), ("1/CU", 1, -1))
 eng = Engine(0)
 for N, D in ((2048, 32), (1000, 16), (4096, 32)):
-    for H in (1, 2, 4, 6, 8, 12, 20, 32):
+    for H in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 6, 8, 12, 20, 32)):
         if N == 4096 and H > 4:
             continue
         comp, cand, vals, hypers = synthetic_problem(N, 16, D, H, 5)
