@@ -107,6 +107,7 @@ class GPEIBase(object):
         # itself refuses calls from a pid other than its creator's (engine.py: Engine._h).
         d = dict(self.__dict__)
         d["_eng"] = None
+        d["_slice_hist"] = {}     # batching statistics of THIS process: timing only, never part of a shipped copy
         return d
 
     # -- persistent state -------------------------------------------------------
@@ -152,13 +153,13 @@ class GPEIBase(object):
 
     # -- log-likelihood data term: host or GPU ------------------------------------------
     def _use_gpu_logprob(self, n):
-        if self.gpu_logprob == "auto":
-            return n >= 16
+        if self.gpu_logprob == "auto":   # threshold measured on one MI355X box; SPX_LOGPROB_MIN_N overrides it
+            return n >= int(os.environ.get("SPX_LOGPROB_MIN_N", "16"))
         return _as_bool(self.gpu_logprob)
 
     def _use_gpu_refine(self, n):
-        if self.gpu_refine == "auto":
-            return True
+        if self.gpu_refine == "auto":    # the GPU wins from N = 8 on; SPX_REFINE_MIN_N keeps the first proposals on the host
+            return n >= int(os.environ.get("SPX_REFINE_MIN_N", "0"))
         return _as_bool(self.gpu_refine)
 
     def data_logprob(self, comp, vals, mean, amp2, noise, ls):

@@ -1234,7 +1234,10 @@ void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double
     // not short of workgroups the whole call follows the diagonal blocks (spx_api.hip decides)
     size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);
     if (alone) lds = 96 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the attribute is per function and device, not per launch: always the larger figure, so that two handles (threads)
+    // with different batch sizes cannot lower it under each other's launch.  A failure shows as a launch error
+    // (checked by the caller's hipGetLastError after the launch).
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipLaunchKernelGGL(k_lean_flow, dim3(nh * ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, tickets,
                        Np, nh, gen, cov, alone ? nullptr : cu_busy);
 }

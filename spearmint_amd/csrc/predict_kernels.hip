@@ -15,6 +15,7 @@
 // (gamma = W (vals - mean), so the second one equals cand_cross^T alpha).
 // beta itself is never written to memory.
 #include "common.h"
+#include "np_sum.h"
 
 #define BM SPX_BM
 #define BN SPX_BN
@@ -612,7 +613,6 @@ void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part
                        htab, time_m, best, ei_draw, mom_m, mom_v, nrb, Mc, nh, c0, M, Mp, h0);
 }
 
-__device__ double np_pairwise(const double* a, int64_t stride, int n);
 
 // EI against S fantasies, averaged over S in numpy's pairwise order
 // (np.mean(ei, axis=1) on the (M, S) array of GPEIChooser.py:261-266).
@@ -678,32 +678,6 @@ void launch_ei_finalize_fant(hipStream_t s, const double* part_ss, const double*
 // loops_utils.h.src pairwise sum: <8 sequential, <=128 eight accumulators,
 // else split in halves rounded to multiples of 8).
 // ---------------------------------------------------------------------------
-__device__ double np_pairwise(const double* a, int64_t stride, int n)
-{
-#pragma clang fp contract(off)
-    if (n < 8) {
-        double res = -0.0;
-        for (int i = 0; i < n; ++i) res += a[i * stride];
-        return res;
-    }
-    if (n <= 128) {
-        double r[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = a[q * stride];
-        int i;
-        for (i = 8; i < n - (n % 8); i += 8) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) r[q] += a[(i + q) * stride];
-        }
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += a[i * stride];
-        return res;
-    }
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return np_pairwise(a, stride, n2) + np_pairwise(a + (int64_t)n2 * stride, stride, n - n2);
-}
-
 __global__ __launch_bounds__(256) void k_mean_over_draws(const double* __restrict__ ei_draw,
                                                          double* __restrict__ ei_mean, int64_t M,
                                                          int64_t Mp, int H)

@@ -41,8 +41,10 @@ def lbfgs_many(eval_batch, points, bounds, log=None, serial=None):
     if serial:
         out = pts.copy()
         for i in range(n):
-            out[i, :] = spo.fmin_l_bfgs_b(lambda x: tuple(v[0] for v in eval_batch(np.asarray(x, dtype=float)[None, :])),
-                                          pts[i, :].flatten(), bounds=bounds, disp=0)[0]
+            def one(x):
+                f, g = eval_batch(np.asarray(x, dtype=float)[None, :])
+                return float(f[0]), np.array(g[0], dtype=float, copy=True)   # as the threaded path hands them over
+            out[i, :] = spo.fmin_l_bfgs_b(one, pts[i, :].flatten(), bounds=bounds, disp=0)[0]
         return out
     cv = threading.Condition()
     state = {"live": n}

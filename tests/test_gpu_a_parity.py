@@ -54,6 +54,19 @@ def test_golden_ei(eng, golden_dir, case):
     assert val == mean[idx]
 
 
+@pytest.mark.parametrize("H", [129, 300, 1100])
+def test_mean_over_more_than_128_draws_is_numpys(eng, H):
+    """np.mean(overall_ei, axis=1) beyond 128 draws: numpy's pairwise halving, walked without recursion on the device
+    (csrc/np_sum.h; the same header is compiled for the host in tests/test_host_logic.py)."""
+    comp, cand, vals, hypers = synthetic_problem(24, 700, 3, H, 1000 + H)
+    idx, val, mean, draws = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    assert np.array_equal(mean, np.mean(draws, axis=1))
+    assert idx == int(np.argmax(mean)) and val == mean[idx]
+    sub = np.arange(0, 700, 7)
+    ref = orc.ei_over_hypers(comp, cand[sub], vals, hypers[:40])
+    assert_ei_close(draws[sub, :40], ref)
+
+
 def test_golden_stage_arrays(eng, golden_dir):
     g = _g(golden_dir, "ei_small_a.npz")
     eng.set_observations(g["comp"], g["vals"]); eng.set_candidates(g["cand"]); eng.set_hypers(g["hypers"])
@@ -88,6 +101,33 @@ def test_golden_persec(eng, golden_dir):
 
 
 # ---- oracle on seeded inputs, per stage ----------------------------------------
+def test_plain_c_client_of_the_abi(eng, tmp_path):
+    """tests/c/abi_client.c -- C99, gcc, no Python, no C++ -- drives libspx through include/spx.h and gets, bit for
+    bit, what the ctypes binding gets: the boundary is a C ABI, not a Python extension."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "spearmint_amd")
+    exe = str(tmp_path / "abi_client")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_client.c"), "-o", exe,
+                           "-L" + libdir, "-lspx", "-Wl,-rpath," + libdir])
+    comp, cand, vals, hypers = synthetic_problem(300, 7000, 6, 4, 80)
+    with open(str(tmp_path / "in.bin"), "wb") as fh:
+        np.array([300, 6, 7000, 4], dtype=np.int64).tofile(fh)
+        for a in (comp, vals, cand, hypers):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(fh)
+    out = subprocess.check_output([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    raw = open(str(tmp_path / "out.bin"), "rb").read()
+    best_idx = int(np.frombuffer(raw, dtype=np.int64, count=1)[0])
+    rest = np.frombuffer(raw, dtype=np.float64, offset=8)
+    best_val, mean, draws, lp = rest[0], rest[1:7001], rest[7001:7001 + 28000].reshape(7000, 4), rest[7001 + 28000:]
+    idx, val, m, d = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    eng.set_hypers(hypers)
+    assert best_idx == idx and best_val == val and np.array_equal(mean, m) and np.array_equal(draws, d)
+    assert np.array_equal(lp, eng.gp_logprob())
+    assert out.decode().startswith("best %d " % idx)
+
+
 @pytest.mark.parametrize("N,M,D,H,seed", [
     (2, 5, 1, 1, 1), (3, 127, 2, 2, 2), (127, 128, 3, 3, 3), (128, 129, 4, 7, 4), (129, 1000, 5, 8, 5),
     (200, 513, 9, 9, 6), (300, 700, 16, 2, 7), (257, 300, 17, 2, 8), (256, 256, 33, 2, 9),

@@ -8,7 +8,7 @@ import pytest
 
 from oracle import gp_ei_oracle as orc
 from spearmint_amd.synthetic import synthetic_problem
-from tests.test_gpu_parity import assert_ei_close
+from tests.test_gpu_a_parity import assert_ei_close
 
 pytestmark = pytest.mark.gpu
 KINDS = ["Matern32", "ARDSE", "SE"]

@@ -233,6 +233,32 @@ def test_device_mean_order_is_numpys(H):
     assert np.array_equal(want, got)
 
 
+def test_device_pairwise_sum_source_is_numpys(tmp_path):
+    """The summation the kernels run (spearmint_amd/csrc/np_sum.h: numpy's pairwise order restated WITHOUT recursion, so
+    no kernel needs a private segment) compiled for the host from that very header and compared with numpy bit for
+    bit: every length up to 1200, the power-of-two edges, strided (column) access as k_mean_over_draws reads it."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "pw.cpp"
+    src.write_text('#define SPX_HD static inline\n#include "np_sum.h"\n'
+                   'extern "C" double pw(const double* a, long stride, int n) { return np_pairwise(a, stride, n); }\n')
+    so = str(tmp_path / "libpw.so")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spearmint_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I" + inc, str(src), "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.pw.restype = ctypes.c_double
+    lib.pw.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int]
+    rs = np.random.RandomState(5)
+    for n in list(range(1, 1201)) + [2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192]:
+        a = rs.randn(n) * 10.0 ** rs.uniform(-6, 6, n)
+        assert lib.pw(a.ctypes.data, 1, n) == np.sum(a), n
+    for H in (20, 129, 300, 1000, 4096):
+        m = np.ascontiguousarray((rs.rand(7, H) * 10.0 ** rs.randint(-20, 3, size=(7, H))))
+        t = np.ascontiguousarray(m.T)                      # [H][M]: the device layout, stride M
+        got = np.array([(0.0 + lib.pw(t.ctypes.data + 8 * c, 7, H)) / H for c in range(7)])
+        assert np.array_equal(got, np.mean(m, axis=1)), H
+
+
 def test_speculative_sampler_is_the_same_markov_chain(golden_dir):
     """util.slice_sample_batched (proposals evaluated in speculative batches, RNG rewound)
     must reproduce util.slice_sample bit for bit -- values and RNG state -- also when the
