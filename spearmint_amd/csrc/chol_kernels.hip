@@ -29,6 +29,16 @@
 #define NB SPX_NB
 #define LDP 66   // LDS row stride (doubles) for MFMA operand tiles: 16 rows x 2 cols hit 32 distinct 8-byte banks
 
+// An MFMA operand out of LDS as ONE ds_read_b64.  Left to itself the compiler pairs the reads of neighbouring contraction
+// steps (32 bytes apart) into ds_read2_b64, and that instruction is serviced in 16-lane groups over 32 banks instead of
+// 32-lane halves over 64: with the operand pattern [16 rows li][k-slot g] at a row stride of 66 (or 18) doubles the lanes
+// li and li + 8 of a group share a bank -- a 2-way conflict, 16 LDS cycles per pair of values where two ds_read_b64 take 4.
+// (k_lean_flow in round 3: 276 ds_read2_b64, SQ_LDS_BANK_CONFLICT = 44 % of SQ_LDS_IDX_ACTIVE, matrix pipes 52 % busy
+// with two workgroups per CU -- LDS-bound.)  A volatile access is never merged; the address-space cast keeps it a DS
+// instruction (a plain volatile generic pointer would become flat_load).
+typedef const volatile double __attribute__((address_space(3))) * lds_cvd_p;
+__device__ __forceinline__ double lds_ld(const double* p) { return *(lds_cvd_p)p; }
+
 __device__ __forceinline__ double readlane_f64(double v, int src)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -74,11 +84,11 @@ __device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B
 {
 #pragma unroll 4
     for (int k0 = 0; k0 < NB; k0 += 4) {
-        double a = A_lds[(16 * wave + li) * LDP + k0 + g];
+        double a = lds_ld(A_lds + (16 * wave + li) * LDP + k0 + g);
         if (negate) a = -a;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const double b = B_lds[(16 * nt + li) * LDP + k0 + g];
+            const double b = lds_ld(B_lds + (16 * nt + li) * LDP + k0 + g);
             acc[nt] = MFMA_F64(a, b, acc[nt]);
         }
     }
@@ -170,8 +180,8 @@ __device__ __forceinline__ d4 inv_partial(const double* S, const double* XT, int
     for (int pb = j; pb < i; ++pb) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const double av = S[(16 * i + li) * LDP + 16 * pb + 4 * ks + g];
-            const double bv = XT[(16 * j + li) * LDP + 16 * pb + 4 * ks + g];
+            const double av = lds_ld(S + (16 * i + li) * LDP + 16 * pb + 4 * ks + g);
+            const double bv = lds_ld(XT + (16 * j + li) * LDP + 16 * pb + 4 * ks + g);
             t4 = MFMA_F64(av, bv, t4);
         }
     }
@@ -197,7 +207,7 @@ __device__ __forceinline__ void inv_finish(const d4& t4, double* XT, const doubl
     d4 o4 = (d4){0.0, 0.0, 0.0, 0.0};
     const double* Ti = T16 + i * 16 * 18;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) o4 = MFMA_F64(-Ti[li * 18 + 4 * ks + g], t4[ks], o4);
+    for (int ks = 0; ks < 4; ++ks) o4 = MFMA_F64(-lds_ld(Ti + li * 18 + 4 * ks + g), t4[ks], o4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         XT[(16 * j + li) * LDP + 16 * i + g + 4 * r] = o4[r];
@@ -214,8 +224,8 @@ __device__ __forceinline__ void trail_tile(double* S, int ti, int tj, int b0, in
     for (int r = 0; r < 4; ++r) c4[r] = S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const double av = -S[(16 * ti + li) * LDP + b0 + 4 * ks + g];
-        const double bv = S[(16 * tj + li) * LDP + b0 + 4 * ks + g];
+        const double av = -lds_ld(S + (16 * ti + li) * LDP + b0 + 4 * ks + g);
+        const double bv = lds_ld(S + (16 * tj + li) * LDP + b0 + 4 * ks + g);
         c4 = MFMA_F64(av, bv, c4);
     }
 #pragma unroll
@@ -304,8 +314,8 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                 d4 c4 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const double av = S[(16 * ti + li) * LDP + b0 + 4 * ks + g];
-                    const double bv = Tb[li * 18 + 4 * ks + g];
+                    const double av = lds_ld(S + (16 * ti + li) * LDP + b0 + 4 * ks + g);
+                    const double bv = lds_ld(Tb + li * 18 + 4 * ks + g);
                     c4 = MFMA_F64(av, bv, c4);
                 }
 #pragma unroll
@@ -722,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_step_ps(double* __restrict__ Lt
         __syncthreads();
         out[b] = (d4){0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < 16 * (b + 1); k0 += 4)
-            out[b] = MFMA_F64(A[(16 * wave + li) * LDP + k0 + g], B[(16 * b + li) * LDP + k0 + g], out[b]);
+            out[b] = MFMA_F64(lds_ld(A + (16 * wave + li) * LDP + k0 + g), lds_ld(B + (16 * b + li) * LDP + k0 + g), out[b]);
     }
     store_tile(row + (size_t)k * LEAN_TILE, out);
 }
@@ -903,7 +913,7 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
         if (b + 1 < 4 && b + 1 < have) dinv_rows_load(Dk, b + 1, dn);
         out[b] = (d4){0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < 16 * (b + 1); k0 += 4)
-            out[b] = MFMA_F64(R[(16 * wave + li) * LDP + k0 + g], B[(16 * b + li) * LDP + k0 + g], out[b]);
+            out[b] = MFMA_F64(lds_ld(R + (16 * wave + li) * LDP + k0 + g), lds_ld(B + (16 * b + li) * LDP + k0 + g), out[b]);
         store_tile_quarter_sc1(dst, out[b], b);      // on its way while the next quarter waits
         if (DIAG) {
             // the owner of the next diagonal block: step lo of tile (i,i), a1 -= L_i,lo L_i,lo^T, follows the solve
@@ -914,9 +924,9 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
             __syncthreads();
 #pragma unroll
             for (int k0 = 0; k0 < 16; k0 += 4) {
-                const double a = -Q[(16 * wave + li) * 18 + k0 + g];
+                const double a = -lds_ld(Q + (16 * wave + li) * 18 + k0 + g);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) a1[nt] = MFMA_F64(a, Q[(16 * nt + li) * 18 + k0 + g], a1[nt]);
+                for (int nt = 0; nt < 4; ++nt) a1[nt] = MFMA_F64(a, lds_ld(Q + (16 * nt + li) * 18 + k0 + g), a1[nt]);
             }
             if (b < 3) __syncthreads();    // Q is rewritten by the next quarter (which may not wait any more)
         }
@@ -1366,8 +1376,8 @@ __global__ __launch_bounds__(1024) void k_lean_trsm(double* __restrict__ Lt, con
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
     for (int k0 = 0; k0 < NB; k0 += 4) {
-        const double a = A[(16 * wr + li) * LDP + k0 + g];
-        const double bv = B[(16 * wc + li) * LDP + k0 + g];
+        const double a = lds_ld(A + (16 * wr + li) * LDP + k0 + g);
+        const double bv = lds_ld(B + (16 * wc + li) * LDP + k0 + g);
         acc = MFMA_F64(a, bv, acc);
     }
     // element (16 wr + g + 4 r, 16 wc + li) = value q = 4 wc + r of tile thread t = 64 wr + lane

@@ -146,3 +146,34 @@ def test_engine_refuses_calls_from_a_forked_child(lib):
     with pytest.raises(engine.SpxError):
         eng.set_option("timing", 0)        # closed
     eng.close()                            # idempotent
+
+
+def test_no_kernel_of_the_shipped_library_needs_scratch(tmp_path):
+    """Every gfx950 kernel in libspx.so has private_segment_fixed_size 0 (no spills, no recursion, no dynamically
+    indexed private arrays).  A kernel with a private segment makes the runtime allocate per-queue scratch behind every
+    stream that runs it -- hundreds of MiB that come and go outside spx_destroy's control (round 3's red
+    test_handles_release_their_device_memory; profiles/r04_leak_probe.log)."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        pytest.skip("no ROCm llvm tools on this box")
+    so = str(tmp_path / "libspx.so")
+    shutil.copy(engine.default_lib_path(), so)
+    subprocess.check_call([os.path.join(llvm, "llvm-objdump"), "--offloading", so], stdout=subprocess.DEVNULL)
+    objs = [f for f in os.listdir(str(tmp_path)) if "amdgcn" in f]
+    assert objs, "no gfx950 code objects found in libspx.so"
+    kernels = {}
+    for f in objs:
+        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / f)]).decode()
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split()[-1]
+            elif line.startswith(".private_segment_fixed_size:") and name:
+                kernels[name] = int(line.split()[-1])
+    assert len(kernels) > 40, sorted(kernels)
+    assert any("k_lean_flow" in k for k in kernels) and any("k_mean_over_draws" in k for k in kernels)
+    with_scratch = {k: v for k, v in kernels.items() if v}
+    assert not with_scratch, with_scratch
