@@ -105,10 +105,29 @@ def pmc_traffic(workload):
     return None, None
 
 
-def cpu_baseline(w, m_cpu=20000, reps=3):
-    """Time the numpy/scipy oracle (port of GPEIChooser.compute_ei x H + argmax) to the spec of
-    SURVEY.md 8(d) / BASELINE.md section 5: same N, D, H; M_cpu = 20 000 candidates in chunks of
-    20 000; one warm-up, then `reps` timed repetitions, median reported."""
+def _reference_chooser(D, H):
+    """The reference's OWN GPEIChooser (S/chooser/GPEIChooser.py), converted for Python 3 by lib2to3: imported from
+    /root/reference where that exists (build container), else from the archive build() wrote (oracle/_ref/chooser_py3.zip,
+    shipped with the tree).  None when neither is there."""
+    from oracle import ref_py3
+    mods = ref_py3.load() if ref_py3.available() else ref_py3.load_shipped()
+    if mods is None:
+        return None
+    import tempfile
+    ch = mods["GPEIChooser"].GPEIChooser(tempfile.mkdtemp(prefix="spx_refbase_"), mcmc_iters=H)
+    ch.D = D
+    return ch
+
+
+def cpu_baseline(w, m_cpu=20000, reps=2):
+    """The CPU figure beside the GPU one (SURVEY.md 8(d) / BASELINE.md section 5: same N, D, H; M_cpu = 20 000
+    candidates; one warm-up, then timed repetitions, median reported), on this box's host cores:
+
+      kind "reference"  the reference's own arithmetic -- its GPEIChooser.compute_ei (GPEIChooser.py:178-208) called
+                        once per hyper-parameter draw into overall_ei[:, draw], then np.argmax(np.mean(...)) exactly as
+                        next() does (:143-153), the draws being the benchmark's fixed ones instead of sample_hypers';
+      kind "port"       the numpy/scipy oracle's restatement of the same (the only one available without the archive);
+                        always timed too (one repetition) and reported beside the reference as `port_value`."""
     from oracle import gp_ei_oracle as orc
     try:
         from threadpoolctl import threadpool_info
@@ -122,20 +141,48 @@ def cpu_baseline(w, m_cpu=20000, reps=3):
     m_cpu = int(min(m_cpu, w["M"]))
     comp, cand, vals, hypers = synthetic_problem(N, m_cpu, D, H, 3000)[:4]
     m_warm = max(256, m_cpu // 10)
-    orc.choose(orc.ei_grid_chunked(comp, cand[:m_warm], vals, hypers, chunk=20000))   # warm-up: BLAS threads, page faults
-    times = []
-    for _ in range(max(1, reps)):
-        t0 = time.time()
-        ei = orc.ei_grid_chunked(comp, cand, vals, hypers, chunk=20000)
-        orc.choose(ei)
-        times.append(time.time() - t0)
-    dt = float(np.median(times))
-    return {"value": m_cpu * H / dt, "unit": "EI evals/s", "cores": int(threads), "kind": "port",
-            "host_cpus": os.cpu_count(), "blas": blas, "numpy": np.__version__, "scipy": scipy.__version__,
-            "reps_s": [round(t, 2) for t in times],
-            "sample": "oracle.ei_grid_chunked (numpy/scipy restatement of GPEIChooser.compute_ei x H + "
-                      "argmax(mean)), N_obs=%d, D=%d, mcmc_iters=%d, %d candidates in chunks of 20000; warm-up on "
-                      "%d candidates, median of %d runs (%.1f s each)" % (N, D, H, m_cpu, m_warm, len(times), dt)}
+
+    def port(c):
+        ei = orc.ei_grid_chunked(comp, c, vals, hypers, chunk=20000)
+        return orc.choose(ei), ei
+
+    ref = _reference_chooser(D, H)
+    pend = np.zeros((0, D))
+
+    def reference(c):
+        overall_ei = np.zeros((c.shape[0], H))
+        for h in range(H):
+            ref.mean, ref.noise, ref.amp2, ref.ls = hypers[h, 0], hypers[h, 1], hypers[h, 2], hypers[h, 3:].copy()
+            overall_ei[:, h] = ref.compute_ei(comp, pend, c, vals)
+        return int(np.argmax(np.mean(overall_ei, axis=1))), overall_ei
+
+    def timed(fn, n):
+        fn(cand[:m_warm])                       # warm-up: BLAS threads, page faults
+        times, res = [], None
+        for _ in range(max(1, n)):
+            t0 = time.time()
+            res = fn(cand)
+            times.append(time.time() - t0)
+        return float(np.median(times)), times, res
+
+    out = {"unit": "EI evals/s", "cores": int(threads), "host_cpus": os.cpu_count(), "blas": blas,
+           "numpy": np.__version__, "scipy": scipy.__version__}
+    dt_p, times_p, (ip, eip) = timed(port, 1 if ref is not None else reps)
+    port_txt = ("oracle.ei_grid_chunked (numpy/scipy restatement of GPEIChooser.compute_ei x H + argmax(mean)), "
+                "N_obs=%d, D=%d, mcmc_iters=%d, %d candidates; warm-up on %d candidates, median of %d runs (%.1f s each)"
+                % (N, D, H, m_cpu, m_warm, len(times_p), dt_p))
+    if ref is None:
+        out.update({"value": m_cpu * H / dt_p, "kind": "port", "reps_s": [round(t, 2) for t in times_p], "sample": port_txt})
+        return out
+    dt_r, times_r, (ir, eir) = timed(reference, reps)
+    out.update({"value": m_cpu * H / dt_r, "kind": "reference", "reps_s": [round(t, 2) for t in times_r],
+                "port_value": m_cpu * H / dt_p, "port_reps_s": [round(t, 2) for t in times_p],
+                "port_equals_reference": bool(ip == ir and np.array_equal(eip, eir)),
+                "sample": "the reference's own GPEIChooser.compute_ei (lib2to3-converted S/chooser/GPEIChooser.py:178-208 "
+                          "+ gp.py) once per draw into overall_ei, then np.argmax(np.mean(overall_ei, axis=1)) (:143-153), "
+                          "N_obs=%d, D=%d, mcmc_iters=%d, %d candidates; warm-up on %d candidates, median of %d runs "
+                          "(%.1f s each); port_value: %s" % (N, D, H, m_cpu, m_warm, len(times_r), dt_r, port_txt)})
+    return out
 
 
 def weak_problem(w, rank):
@@ -272,7 +319,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-candidates", type=int, default=20000)
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--skip-extras", action="store_true", help="do not time the strong-scaling c4 / c5 sub-records")
     ap.add_argument("--extra-steps", type=int, default=2, help="timed steps of each strong-scaling sub-record (after 1 warm-up)")
     ap.add_argument("--hyper-shards", type=int, default=1,

@@ -84,6 +84,12 @@ int  spx_multi_query(spx_handle* h, int32_t* n_dev, int32_t* transport, int32_t*
  * index_base).                                                                                     */
 #define SPX_COMM_ID_BYTES 128
 int  spx_comm_unique_id(char* id_out /* SPX_COMM_ID_BYTES */);
+/* librccl is bound at run time (dlopen; SPX_RCCL_LIB overrides the name) through hand-declared types, so the loaded
+ * library's ncclGetVersion is checked before anything else of it is called: NCCL API 2.10 <= version < 3.0 (tested
+ * with RCCL 2.27.7); anything else, or a library without ncclGetVersion, is refused with SPX_ERR_HIP and a message
+ * naming the version (SPX_RCCL_ANY_VERSION=1 waives the range).  Returns the loaded library's version code
+ * (22707 = 2.27.7) in *version_code; loads the library if it is not loaded yet.                                */
+int  spx_rccl_version(int32_t* version_code);
 int  spx_comm_attach(spx_handle* h, const char* id, int32_t nranks, int32_t rank);
 /* Optional 2-D partition, "hypers x candidates" (SURVEY.md 8(e)): P = hyper_shards x P_c devices / ranks, device
  * r = rc * hyper_shards + rh evaluates the draws of hyper shard rh for the candidates of shard rc, and the path's

@@ -52,7 +52,14 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    int version = 0;                 // ncclGetVersion's code: 22707 = 2.27.7
 };
+// What the hand-declared types above are known to match: ncclUniqueId of 128 bytes, ncclChar = 0, ncclFloat64 = 8,
+// ncclSum = 0, (sendbuf, recvbuf, count, type, [op,] comm, stream) -- the NCCL 2 API since the version code took the form
+// X * 10000 + Y * 100 + Z (2.9).  Tested on this pool: RCCL 2.27.7.
+#define SPX_RCCL_MIN_VERSION 21000
+#define SPX_RCCL_MAX_VERSION 30000
 
 static int load_rccl(RcclApi* r)
 {
@@ -77,6 +84,20 @@ static int load_rccl(RcclApi* r)
         *(void**)&a.GroupStart = dlsym(lib, "ncclGroupStart");
         *(void**)&a.GroupEnd = dlsym(lib, "ncclGroupEnd");
         *(void**)&a.GetErrorString = dlsym(lib, "ncclGetErrorString");
+        *(void**)&a.GetVersion = dlsym(lib, "ncclGetVersion");
+        // the version first: nothing else of a library we do not know is called, no struct is passed to it
+        if (!a.GetVersion || a.GetVersion(&a.version) != ncclSuccess) {
+            dlclose(lib);
+            return fail(SPX_ERR_HIP, "spx_create_multi: the loaded librccl has no usable ncclGetVersion");
+        }
+        const char* any = getenv("SPX_RCCL_ANY_VERSION");
+        if ((a.version < SPX_RCCL_MIN_VERSION || a.version >= SPX_RCCL_MAX_VERSION) && !(any && *any && *any != '0')) {
+            const int v = a.version;
+            dlclose(lib);
+            return fail(SPX_ERR_HIP, "spx_create_multi: librccl reports version code %d; this build binds the NCCL 2 API "
+                        "by hand and accepts %d <= code < %d (tested: 22707 = RCCL 2.27.7); set SPX_RCCL_ANY_VERSION=1 to "
+                        "try anyway", v, SPX_RCCL_MIN_VERSION, SPX_RCCL_MAX_VERSION);
+        }
         if (!a.CommInitAll || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
             dlclose(lib);
             return fail(SPX_ERR_HIP, "spx_create_multi: librccl lacks an expected symbol");
@@ -504,6 +525,15 @@ void spx_comm_release(spx_handle* k)
 static int multi_set_partition(spx_multi* m, int32_t hyper_shards);
 
 extern "C" {
+
+int spx_rccl_version(int32_t* version_code)
+{
+    RcclApi api;
+    int rc = load_rccl(&api);
+    if (rc) return rc;
+    if (version_code) *version_code = api.version;
+    return SPX_OK;
+}
 
 int spx_create_multi(const int* device_ids, int32_t n_dev, spx_handle** out)
 {

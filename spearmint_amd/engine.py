@@ -39,6 +39,7 @@ ABI = {
     "spx_create_multi": (ctypes.c_int, [_c_int32_p, ctypes.c_int32, ctypes.POINTER(_vp)]),
     "spx_multi_query": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p, _c_int32_p, ctypes.c_int32]),
     "spx_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "spx_rccl_version": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int32)]),
     "spx_comm_attach": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]),
     "spx_set_partition": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
     "spx_destroy": (None, [_vp]),
@@ -441,6 +442,16 @@ class Engine(object):
 def device_count(lib=None):
     n = load_library(lib).spx_device_count()
     return n if n > 0 else 0
+
+
+def rccl_version(lib=None):
+    """Version code of the librccl that libspx binds (22707 = 2.27.7); SpxError when it cannot be loaded or is outside
+    the range the hand-declared binding accepts (include/spx.h: spx_rccl_version)."""
+    l = load_library(lib)
+    v = ctypes.c_int32(0)
+    if l.spx_rccl_version(ctypes.byref(v)) != 0:
+        raise SpxError(l.spx_last_error().decode("utf-8", "replace"))
+    return int(v.value)
 
 
 class MultiEngine(Engine):

@@ -177,3 +177,65 @@ def test_no_kernel_of_the_shipped_library_needs_scratch(tmp_path):
     assert any("k_lean_flow" in k for k in kernels) and any("k_mean_over_draws" in k for k in kernels)
     with_scratch = {k: v for k, v in kernels.items() if v}
     assert not with_scratch, with_scratch
+
+
+_FAKE_RCCL = r"""
+#include <stddef.h>
+static int calls = 0;
+int ncclGetVersion(int* v) { *v = FAKE_VERSION; return 0; }
+int ncclCommInitAll(void* c, int n, const int* d) { ++calls; return 1; }
+int ncclGetUniqueId(void* id) { ++calls; return 1; }
+int ncclCommInitRank(void* c, int n, ...) { ++calls; return 1; }
+int ncclCommDestroy(void* c) { ++calls; return 1; }
+int ncclAllGather(const void* a, void* b, size_t n, int t, void* c, void* s) { ++calls; return 1; }
+int ncclAllReduce(const void* a, void* b, size_t n, int t, int o, void* c, void* s) { ++calls; return 1; }
+int ncclGroupStart(void) { ++calls; return 1; }
+int ncclGroupEnd(void) { ++calls; return 1; }
+const char* ncclGetErrorString(int r) { return "fake"; }
+int fake_calls(void) { return calls; }
+"""
+
+
+def _in_child_with_fake_rccl(so, q):
+    os.environ["SPX_RCCL_LIB"] = so
+    from spearmint_amd import engine as e
+    lib = e.load_library()
+    out = {}
+    try:
+        out["version"] = e.rccl_version()
+    except e.SpxError as err:
+        out["version_error"] = str(err)
+    import ctypes
+    h = ctypes.c_void_p()
+    ids = (ctypes.c_int * 2)(0, 1)
+    out["create_rc"] = lib.spx_create_multi(ids, 2, ctypes.byref(h))
+    out["create_error"] = lib.spx_last_error().decode()
+    out["fake_calls"] = ctypes.CDLL(so).fake_calls()
+    q.put(out)
+
+
+@pytest.mark.parametrize("code,ok", [(30100, False), (2804, False), (22707, True)])
+def test_foreign_rccl_version_is_an_error_code_not_a_crash(tmp_path, code, ok):
+    """The RCCL binding is declared by hand (csrc/spx_multi.hip), so the library that dlopen finds is asked for its
+    version before anything else of it is called: a librccl outside 2.10 <= v < 3.0 yields SPX_ERR_HIP with the
+    version in the message from spx_create_multi / spx_rccl_version, and none of its other entry points has run."""
+    import multiprocessing
+    import subprocess
+    src = tmp_path / "fake_rccl.c"
+    src.write_text(_FAKE_RCCL)
+    so = str(tmp_path / ("librccl_fake_%d.so" % code))
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-DFAKE_VERSION=%d" % code, str(src), "-o", so])
+    ctx = multiprocessing.get_context("spawn")      # the binding is loaded once per process
+    q = ctx.Queue()
+    p = ctx.Process(target=_in_child_with_fake_rccl, args=(so, q))
+    p.start()
+    out = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    if ok:
+        assert out.get("version") == code
+        assert out["create_rc"] != 0 and "ncclCommInitAll" in out["create_error"]   # the fake refuses, as an error code
+    else:
+        assert str(code) in out["version_error"] and "version" in out["version_error"]
+        assert out["create_rc"] == engine.SPX_ERR_HIP and str(code) in out["create_error"]
+        assert out["fake_calls"] == 0

@@ -190,3 +190,20 @@ def test_other_covariances_match_reference(golden_dir, kname):
                 assert np.isclose(f, f_ref, rtol=1e-12, atol=0) and np.allclose(gr, g_ref, rtol=1e-10, atol=1e-300)
     # the default is untouched afterwards
     assert orc._active_covar == "Matern52"
+
+
+def test_bench_cpu_baseline_times_the_reference_itself():
+    """bench.py's `cpu_baseline`: with the reference tree (build container) or build()'s archive oracle/_ref/chooser_py3.zip
+    (GPU box) present the timed CPU code is the reference's OWN GPEIChooser.compute_ei loop (kind "reference") and the
+    oracle's restatement, timed beside it, returns the same EI matrix bit for bit; without either it is the port."""
+    import bench
+    from oracle import ref_py3
+    w = {"N": 60, "D": 3, "H": 4, "M": 5000}
+    have = ref_py3.available() or os.path.isfile(ref_py3.CHOOSER_ZIP)
+    out = bench.cpu_baseline(w, 700, 1)
+    assert out["unit"] == "EI evals/s" and out["value"] > 0 and out["cores"] >= 1
+    if have:
+        assert out["kind"] == "reference" and out["port_equals_reference"] is True and out["port_value"] > 0
+        assert "GPEIChooser.compute_ei" in out["sample"]
+    else:
+        assert out["kind"] == "port"
