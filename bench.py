@@ -241,8 +241,7 @@ def main_in_process(args):
     def run(nsteps):
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            eng.factor()
-            eng.ei_run(flags)
+            eng.ei_step(flags)
             out = eng.best()
         return time.perf_counter() - t0, out
 
@@ -285,8 +284,7 @@ def main_in_process(args):
                 def srun(k):
                     t0 = time.perf_counter()
                     for _ in range(k):
-                        eng.factor()
-                        eng.ei_run(fl)
+                        eng.ei_step(fl)
                         o = eng.best()
                     return time.perf_counter() - t0, o
                 srun(1)
@@ -436,8 +434,7 @@ def main():
         sync()
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            e.factor()
-            e.ei_run(fl)
+            e.ei_step(fl)                   # spx_factor + spx_ei_run, one host synchronisation
             idx, val = e.best()
             out = (idx, val) if lib else spx_dist.exchange_best(val, idx, device=tdev)
         if torch is not None and torch.cuda.is_available():
@@ -640,8 +637,7 @@ def main():
                     e3.set_partition(args.hyper_shards, cfg["M"], cfg["H"])
 
             def step_2d():
-                e3.factor()
-                e3.ei_run(0)
+                e3.ei_step(0)
                 if use_lib:                                       # ncclAllReduce + argmax ran inside spx_ei_run
                     return e3.best()
                 sums = np.sum(e3.ei_draws(), axis=1)              # this rank's draws, its candidates: D2H of M_local x H_local

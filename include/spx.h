@@ -149,8 +149,15 @@ int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, in
  * mean/variance (:198-199), EI (:202-206) for every (candidate, draw); then the
  * MCMC mean and the argmax (:153).  Results stay on the device.               */
 int spx_ei_run(spx_handle* h, int32_t flags);
+/* spx_factor followed by spx_ei_run as ONE call with ONE host synchronisation: the body of a chooser's next() for fixed
+ * hyper-parameter draws (GPEIChooser.py:143-153: compute_ei per draw, argmax of the mean) and bench.py's timed step.
+ * Same kernels and results as the two calls; a covariance that is not positive definite is reported as spx_factor
+ * reports it (SPX_ERR_NOT_PD + spx_not_pd_info) once the step's single synchronisation has passed.  Fantasies set
+ * before the call are dropped, as by spx_factor.  What it saves matters at small N (N = 128, 20 000 candidates, 10
+ * draws: two synchronisations + three device-to-host copies were ~85 us of a 310 us step).                        */
+int spx_ei_step(spx_handle* h, int32_t flags);
 
-/* results of the last spx_ei_run */
+/* results of the last spx_ei_run / spx_ei_step */
 /* best_idx = index_base + argmax_c mean_h EI[c,h]  with numpy's rule (first NaN
  * wins, else first maximum); best_val = that mean EI.                         */
 int spx_get_best(spx_handle* h, int64_t* best_idx, double* best_val);

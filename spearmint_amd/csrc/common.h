@@ -88,6 +88,12 @@ void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, con
                          const double* dkt, int S, const double* gammaS, const double* alphaS,
                          const double* bests, double* uvec);
 
+// fused_kernels.hip: the whole EI pass of a chunk for N <= 128 in one launch (no K* / beta in memory)
+void launch_ei_fused128(hipStream_t s, int kind, const double* WT, const double* gamma, const double* Xs, const double* s1,
+                        const double* Cs, const double* s2, const double* htab, const double* time_m, double best,
+                        double* ei_draw, double* mom_m, double* mom_v, int N, int Mc, int Dp, int nh, int64_t c0,
+                        int64_t M, int64_t Mp, int n_cu);
+
 // sobol_kernels.hip
 void launch_sobol_grid(hipStream_t s, const uint32_t* dirs, int dim, int64_t n, int64_t skip, double* out);
 
@@ -109,5 +115,5 @@ void launch_mean_over_draws(hipStream_t s, const double* ei_draw, double* ei_mea
 void launch_sum_over_draws(hipStream_t s, const double* ei_draw, double* out, int64_t M, int64_t Mp, int H);
 void launch_div_scalar(hipStream_t s, double* v, int64_t n, double denom);
 void launch_argmax(hipStream_t s, const double* v, int64_t M, double* blk_val, int64_t* blk_idx,
-                   double* out_val, int64_t* out_idx);
+                   double* out_val, int64_t* out_idx, double* host_mirror = nullptr, const int* info = nullptr, int n_info = 0);
 int argmax_blocks(int64_t M);

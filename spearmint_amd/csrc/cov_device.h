@@ -85,14 +85,13 @@ __device__ __forceinline__ void exp_neg(const double (&t)[W], double (&out)[W])
 //   the closing fma(t, 0, .) -- 0 for finite t, NaN otherwise.
 //   The polynomial (1 + sqrt5 r) + (5/3) r2 keeps the reference's association; sqrt and exp are
 //   ~1 ulp device implementations.
+// (the *_t forms take t = (gram - s1) - s2 already formed: the fused small-N EI kernel runs values of DIFFERENT rows in
+// lock step; per value the instruction sequence -- and so the bits -- are the same)
 template <int W>
-__device__ __forceinline__ void matern52_corr(const double (&g)[W], double s1, const double (&s2)[W],
-                                              double (&out)[W])
+__device__ __forceinline__ void matern52_corr_t(const double (&t)[W], double (&out)[W])
 {
 #pragma clang fp contract(off)
-    double t[W], r2[W], r[W], sr[W], e[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+    double r2[W], r[W], sr[W], e[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) r2[w] = __builtin_fmin(__builtin_fmax(-t[w], 1e-300), 1.28e5);
     sqrt_pos<W>(r2, r);
@@ -105,17 +104,24 @@ __device__ __forceinline__ void matern52_corr(const double (&g)[W], double s1, c
         out[w] = fma(t[w], 0.0, poly * e[w]);
     }
 }
+template <int W>
+__device__ __forceinline__ void matern52_corr(const double (&g)[W], double s1, const double (&s2)[W],
+                                              double (&out)[W])
+{
+#pragma clang fp contract(off)
+    double t[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+    matern52_corr_t<W>(t, out);
+}
 
 // Matern-3/2 (gp.py:107-113): r = sqrt(dist2); (1 + sqrt3 r) exp(-sqrt3 r).  Same clamps as above
 // (sqrt3 r > 800 beyond r2 = 2.1e5).
 template <int W>
-__device__ __forceinline__ void matern32_corr(const double (&g)[W], double s1, const double (&s2)[W],
-                                              double (&out)[W])
+__device__ __forceinline__ void matern32_corr_t(const double (&t)[W], double (&out)[W])
 {
 #pragma clang fp contract(off)
-    double t[W], r2[W], r[W], sr[W], e[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+    double r2[W], r[W], sr[W], e[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) r2[w] = __builtin_fmin(__builtin_fmax(-t[w], 1e-300), 2.1e5);
     sqrt_pos<W>(r2, r);
@@ -125,22 +131,39 @@ __device__ __forceinline__ void matern32_corr(const double (&g)[W], double s1, c
 #pragma unroll
     for (int w = 0; w < W; ++w) out[w] = fma(t[w], 0.0, (1.0 + sr[w]) * e[w]);
 }
+template <int W>
+__device__ __forceinline__ void matern32_corr(const double (&g)[W], double s1, const double (&s2)[W],
+                                              double (&out)[W])
+{
+#pragma clang fp contract(off)
+    double t[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+    matern32_corr_t<W>(t, out);
+}
 
 // squared exponential (gp.py:95-100; SE :87-93 is the same with unit length scales):
 // exp(-0.5 dist2); 0.5 r2 > 800 underflows to 0 either way.
 template <int W>
-__device__ __forceinline__ void ardse_corr(const double (&g)[W], double s1, const double (&s2)[W],
-                                           double (&out)[W])
+__device__ __forceinline__ void ardse_corr_t(const double (&t)[W], double (&out)[W])
 {
 #pragma clang fp contract(off)
-    double t[W], hr[W], e[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+    double hr[W], e[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) hr[w] = 0.5 * __builtin_fmin(__builtin_fmax(-t[w], 0.0), 1600.0);
     exp_neg<W>(hr, e);
 #pragma unroll
     for (int w = 0; w < W; ++w) out[w] = fma(t[w], 0.0, e[w]);
+}
+template <int W>
+__device__ __forceinline__ void ardse_corr(const double (&g)[W], double s1, const double (&s2)[W],
+                                           double (&out)[W])
+{
+#pragma clang fp contract(off)
+    double t[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) t[w] = (g[w] - s1) - s2[w];
+    ardse_corr_t<W>(t, out);
 }
 
 template <int KIND, int W>
@@ -152,3 +175,11 @@ __device__ __forceinline__ void corr_of_kind(const double (&g)[W], double s1, co
     else ardse_corr<W>(g, s1, s2, out);
 }
 
+
+template <int KIND, int W>
+__device__ __forceinline__ void corr_of_kind_t(const double (&t)[W], double (&out)[W])
+{
+    if (KIND == SPX_COV_MATERN52) matern52_corr_t<W>(t, out);
+    else if (KIND == SPX_COV_MATERN32) matern32_corr_t<W>(t, out);
+    else ardse_corr_t<W>(t, out);
+}

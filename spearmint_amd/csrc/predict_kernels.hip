@@ -16,6 +16,7 @@
 // beta itself is never written to memory.
 #include "common.h"
 #include "np_sum.h"
+#include "ei_device.h"
 
 #define BM SPX_BM
 #define BN SPX_BN
@@ -547,32 +548,6 @@ void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const dou
 #undef SPX_GO
 }
 
-// ---------------------------------------------------------------------------
-// EI from the partial sums.  Phi follows scipy.special.ndtr (cephes): erf for
-// |x|/sqrt2 < 1/sqrt2, erfc otherwise, so the lower tail keeps relative
-// accuracy; phi = exp(-u^2/2)/sqrt(2 pi) as scipy.stats.norm.pdf.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double ndtr_dev(double a)
-{
-#pragma clang fp contract(off)
-    const double x = a * 0.70710678118654752440;
-    const double z = fabs(x);
-    if (z < 0.70710678118654752440) return 0.5 + 0.5 * erf(x);
-    double y = 0.5 * erfc(z);
-    if (x > 0) y = 1.0 - y;
-    return y;
-}
-
-__device__ __forceinline__ double ei_dev(double func_m, double func_v, double best)
-{
-#pragma clang fp contract(off)
-    const double func_s = sqrt(func_v);  // NaN for func_v < 0, as np.sqrt
-    const double u = (best - func_m) / func_s;
-    const double ncdf = ndtr_dev(u);
-    const double npdf = exp(-(u * u) / 2.0) / 2.50662827463100050242;  // sqrt(2 pi)
-    return func_s * (u * ncdf + npdf);
-}
-
 // one thread per (candidate of the chunk, draw of the group)
 __global__ __launch_bounds__(256) void k_ei_finalize(
     const double* __restrict__ part_ss, const double* __restrict__ part_bg,
@@ -781,9 +756,12 @@ __global__ __launch_bounds__(256) void k_argmax_stage1(const double* __restrict_
     if (threadIdx.x == 0) { bv[blockIdx.x] = best; bi[blockIdx.x] = besti; }
 }
 
+// host_mirror (optional, pinned host memory the device can write): {double value, int64 index, int info[n_info]} -- the
+// winner and the factorisation's not-PD flags reach the host with the kernel's own stores, no copy commands behind it
 __global__ __launch_bounds__(256) void k_argmax_stage2(const double* __restrict__ bv,
                                                        const int64_t* __restrict__ bi, int nb,
-                                                       double* __restrict__ ov, int64_t* __restrict__ oi)
+                                                       double* __restrict__ ov, int64_t* __restrict__ oi,
+                                                       double* __restrict__ host_mirror, const int* __restrict__ info, int n_info)
 {
     double best = 0.0;
     int64_t besti = -1;
@@ -791,12 +769,20 @@ __global__ __launch_bounds__(256) void k_argmax_stage2(const double* __restrict_
         if (better(bv[i], bi[i], best, besti)) { best = bv[i]; besti = bi[i]; }
     block_argmax(best, besti);
     if (threadIdx.x == 0) { *ov = best; *oi = besti; }
+    if (host_mirror) {
+        if (threadIdx.x == 0) {
+            host_mirror[0] = best;
+            reinterpret_cast<int64_t*>(host_mirror)[1] = besti;
+        }
+        int* io = reinterpret_cast<int*>(host_mirror + 2);
+        for (int i = threadIdx.x; i < n_info; i += 256) io[i] = info[i];
+    }
 }
 
 void launch_argmax(hipStream_t s, const double* v, int64_t M, double* blk_val, int64_t* blk_idx,
-                   double* out_val, int64_t* out_idx)
+                   double* out_val, int64_t* out_idx, double* host_mirror, const int* info, int n_info)
 {
     const int nb = argmax_blocks(M);
     hipLaunchKernelGGL(k_argmax_stage1, dim3(nb), dim3(256), 0, s, v, M, blk_val, blk_idx);
-    hipLaunchKernelGGL(k_argmax_stage2, dim3(1), dim3(256), 0, s, blk_val, blk_idx, nb, out_val, out_idx);
+    hipLaunchKernelGGL(k_argmax_stage2, dim3(1), dim3(256), 0, s, blk_val, blk_idx, nb, out_val, out_idx, host_mirror, info, n_info);
 }

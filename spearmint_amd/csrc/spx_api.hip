@@ -44,6 +44,8 @@ static int ensure_init(spx_handle* h)
         for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev_sync[i], hipEventDisableTiming));
         HIPCHK(hipEventCreate(&h->ev_t0));
         HIPCHK(hipEventCreate(&h->ev_t1));
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu > 0) h->n_cu = ncu;
         h->inited = true;
     }
     return SPX_OK;
@@ -174,6 +176,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_lazy")) {   // log-likelihood path: trailing updates two steps at a time (1), one (0), by size (-1, default)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "ei_fused")) {       // N <= 128, no fantasies: K* -> beta -> EI of a chunk in one kernel (1, default) or the general three-stage path (0)
+        h->ei_fused = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
     if (!strcmp(name, "ei_flow")) {        // spx_factor through k_lean_flow (1, default), the left-looking launches (0)
@@ -574,11 +580,50 @@ static void plan_chunks(const spx_handle* h, int64_t* Mc, int* Hb)
     *Hb = (int)hb;
 }
 
+// factor_pending (spx_ei_step): the factorisation is queued on the stream but not yet checked -- its not-PD flags travel
+// home with the winner, and ONE synchronisation ends the step
+static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending);
+
 int spx_ei_run(spx_handle* h, int32_t flags)
 {
     if (!h) return fail(SPX_ERR_ARG, "spx_ei_run: null handle");
     if (h->multi) return spx_multi_ei_run(h->multi, flags);
-    if (!h->factored) return fail(SPX_ERR_ARG, "spx_ei_run: call spx_factor first");
+    return ei_run_impl(h, flags, false);
+}
+
+// spx_factor + spx_ei_run as ONE call with ONE host round trip (what a chooser's next() and bench.py's step are): at small
+// N the two synchronisations and the device-to-host copies behind them were a quarter of the step (N = 128, 20 000
+// candidates, 10 draws: ~85 of 310 us).  Same kernels, same results; a covariance that is not positive definite is
+// reported exactly as spx_factor reports it (SPX_ERR_NOT_PD, spx_not_pd_info), after the one synchronisation.
+int spx_ei_step(spx_handle* h, int32_t flags)
+{
+    if (!h) return fail(SPX_ERR_ARG, "spx_ei_step: null handle");
+    if (h->multi) {
+        int rc = spx_multi_factor(h->multi);
+        return rc ? rc : spx_multi_ei_run(h->multi, flags);
+    }
+    if (h->timing || (flags & SPX_FLAG_TIMING) || !h->have_cand) {   // stage timers bracket each call: keep the two-call form
+        int rc = spx_factor(h);
+        return rc ? rc : ei_run_impl(h, flags, false);
+    }
+    h->handoff_timeout = false;
+    int rc = do_factor(h, false, false, true);
+    if (rc) return rc;
+    h->S = 0;                      // a new factorisation drops the fantasies (finish_factor), here before the run
+    rc = ei_run_impl(h, flags, true);
+    if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {   // as in spx_factor: bounded, then the launches
+        fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
+        h->lean_flow = 0;
+        h->handoff_timeout = false;
+        rc = spx_factor(h);
+        return rc ? rc : ei_run_impl(h, flags, false);
+    }
+    return rc;
+}
+
+static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
+{
+    if (!h->factored && !factor_pending) return fail(SPX_ERR_ARG, "spx_ei_run: call spx_factor first");
     if (!h->have_cand) return fail(SPX_ERR_ARG, "spx_ei_run: no candidates set");
     const bool per_sec = (flags & SPX_FLAG_PER_SEC) != 0;
     const bool keep_mom = (flags & SPX_FLAG_KEEP_MOMENTS) != 0;
@@ -603,22 +648,25 @@ int spx_ei_run(spx_handle* h, int32_t flags)
         }
     }
 
-    const int ns = h->nstreams;
+    // N <= 128 without fantasies: the whole EI pass of a chunk -- K(X,X*), beta = W K*, the moments, EI -- is one kernel
+    // with K* and beta in registers (fused_kernels.hip; option ei_fused); same bits as the three-stage path below
+    const bool fused = Np == SPX_PADN && S == 0 && h->ei_fused != 0;
+    const int ns = fused ? 1 : h->nstreams;
     for (int b = 0; b < 2; ++b) {
         // scaled candidates (all draws) and predicted durations are double-buffered by chunk parity,
         // the K(X*,X) staging buffer and the partial sums by stream
         if ((rc = h->Cs[b].reserve((size_t)H * Mc * Dp * 8))) return rc;
         if ((rc = h->s2[b].reserve((size_t)H * Mc * 8))) return rc;
         if (per_sec && (rc = h->time_m[b].reserve((size_t)H * Mc * 8))) return rc;
-        if (b < ns) {
+        if (b < ns && !fused) {
             if ((rc = h->Kst[b].reserve((size_t)Hb * Np * Mc * 8))) return rc;
             if (S > 0 && (rc = h->part_bgS[b].reserve((size_t)nrb * 2 * S * Mc * 8))) return rc;
         }
     }
     // column sums of beta^2 and beta*gamma per row block for ALL draws of a chunk: written by the
     // GEMM launches and read by one EI-finalize launch per chunk, all on the consumer stream
-    if ((rc = h->part_ss[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
-    if ((rc = h->part_bg[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
+    if (!fused && (rc = h->part_ss[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
+    if (!fused && (rc = h->part_bg[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
     if (S > 128 && (rc = h->scratch.reserve((size_t)S * Mc * 8))) return rc;
     if ((rc = h->ei_draw.reserve((size_t)H * Mp * 8))) return rc;
     if ((rc = h->ei_mean.reserve((size_t)Mp * 8))) return rc;
@@ -671,7 +719,11 @@ int spx_ei_run(spx_handle* h, int32_t flags)
                                     (size_t)std::min<int64_t>(mc, Mp - c0) * 8, (size_t)H, hipMemcpyDeviceToDevice, P));
         // 2 * cand / ls and |cand / ls|^2 for every draw (one launch per chunk)
         TIMED_S(ST_SCALE, P, launch_scale_rows(P, xc, nreal, mc, D, Dp, ls, hs, H, 2.0, Cs, s2));
-        for (int h0 = 0; h0 < H; h0 += Hb, ++item) {
+        if (fused)
+            TIMED_S(ST_PREDICT_GEMM, G, launch_ei_fused128(G, dev_kind(h), h->WT.d(), h->gamma.d(), h->Xs.d(), h->s1.d(), Cs, s2,
+                                                           h->htab.d(), tm, h->best, h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
+                                                           keep_mom ? h->mom_v.d() : nullptr, (int)N, mc, Dp, H, c0, M, Mp, h->n_cu));
+        for (int h0 = 0; h0 < (fused ? 0 : H); h0 += Hb, ++item) {
             const int nhb = std::min(Hb, H - h0);
             const int k = (ns == 2) ? (item & 1) : 0;
             if (ns == 2 && item >= 2) HIPCHK(hipStreamWaitEvent(P, h->ev_sync[2 + k], 0));   // buffer k consumed
@@ -697,7 +749,7 @@ int spx_ei_run(spx_handle* h, int32_t flags)
                                                                    S > 128 ? h->scratch.d() : nullptr));
             if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[2 + k], G));
         }
-        if (S == 0)   // every draw of the chunk in one launch
+        if (S == 0 && !fused)   // every draw of the chunk in one launch
             TIMED_S(ST_EI_FINALIZE, G, launch_ei_finalize(G, h->part_ss[0].d(), h->part_bg[0].d(), h->htab.d(), tm, h->best,
                                                           h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
                                                           keep_mom ? h->mom_v.d() : nullptr, nrb, mc, H, c0, M, Mp, 0));
@@ -707,16 +759,24 @@ int spx_ei_run(spx_handle* h, int32_t flags)
         HIPCHK(hipEventRecord(h->ev_sync[0], P));
         HIPCHK(hipStreamWaitEvent(G, h->ev_sync[0], 0));
     }
+    // the winner (and, in a step, the factorisation's flags) go home through pinned memory with the last kernel's own stores
+    const int n_info = factor_pending ? h->nmodels * H : 0;
+    if ((rc = h->pin_res.reserve(16 + (size_t)n_info * sizeof(int)))) return rc;
+    double* mirror = (double*)h->pin_res.p;
     TIMED(ST_MEAN_ARGMAX, {
         launch_mean_over_draws(s, h->ei_draw.d(), h->ei_mean.d(), M, Mp, H);
         launch_argmax(s, h->ei_mean.d(), M, h->am_val.d(), (int64_t*)h->am_idx.p, h->am_out_val.d(),
-                      (int64_t*)h->am_out_idx.p);
+                      (int64_t*)h->am_out_idx.p, mirror, (const int*)h->info.p, n_info);
     });
     HIPCHK(hipEventRecord(t1, s));
-    HIPCHK(hipMemcpyAsync(&h->best_val, h->am_out_val.p, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&h->best_idx, h->am_out_idx.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
+    h->best_val = mirror[0];
+    h->best_idx = ((const int64_t*)mirror)[1];
+    if (factor_pending) {
+        std::vector<int> info((const int*)(mirror + 2), (const int*)(mirror + 2) + n_info);
+        if ((rc = finish_factor(h, info, false, false))) { h->ran = false; return rc; }
+    }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, t0, t1);
     if (h->timing) {
@@ -928,8 +988,7 @@ static int run_grid(spx_handle* h, const double* comp, const double* vals, const
     if ((rc = spx_set_candidates(h, cand, M, D, 0))) return rc;
     if ((rc = spx_set_hypers(h, hypers, H))) return rc;
     if (log_durs && (rc = spx_set_time_model(h, log_durs, time_hypers))) return rc;
-    if ((rc = spx_factor(h))) return rc;
-    if ((rc = spx_ei_run(h, flags))) return rc;
+    if ((rc = spx_ei_step(h, flags))) return rc;
     if ((rc = spx_get_best(h, best_idx, best_val))) return rc;
     if (ei_mean_out && (rc = spx_get_ei_mean(h, ei_mean_out))) return rc;
     if (ei_draw_out && (rc = spx_get_ei_draws(h, ei_draw_out))) return rc;

@@ -127,6 +127,8 @@ struct spx_handle {
     int lean_ps = -1;                                               // option "lean_ps": 0 / 1 / -1 = default (on)
     DevBuf ps_flags;                                                // k_lean_step_ps: progress of every diagonal block, [H][nblk]
     int lean_flow = -1;                                             // option "lean_flow": whole factorisation in one launch (k_lean_flow)
+    int ei_fused = -1;                                              // option "ei_fused": N <= 128 without fantasies: the EI pass of a chunk as ONE kernel (k_ei_fused128) 1 / 0 / -1 = default (on)
+    int n_cu = 256;                                                 // compute units of the device (ensure_init)
     int ei_flow = -1;                                               // option "ei_flow": spx_factor through k_lean_flow 1 / 0 / -1 = default (on)
     bool factor_tiled = false;                                      // the EI path's factor is tile-major (k_lean_flow made it)
     int lean_flow_cov = -1;                                         // option "lean_flow_cov": K(X,X) built inside k_lean_flow 1 / 0 / -1 = default (on)

@@ -53,6 +53,7 @@ ABI = {
     "spx_factor": (ctypes.c_int, [_vp]),
     "spx_set_fantasies": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, ctypes.c_int32]),
     "spx_ei_run": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "spx_ei_step": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "spx_get_best": (ctypes.c_int, [_vp, _c_int64_p, _c_double_p]),
     "spx_get_ei_mean": (ctypes.c_int, [_vp, _c_double_p]),
     "spx_get_ei_draws": (ctypes.c_int, [_vp, _c_double_p]),
@@ -285,6 +286,10 @@ class Engine(object):
 
     def ei_run(self, flags=0):
         self._check(self._lib.spx_ei_run(self._h, int(flags)))
+
+    def ei_step(self, flags=0):
+        """factor() + ei_run() with one host synchronisation (include/spx.h: spx_ei_step)."""
+        self._check(self._lib.spx_ei_step(self._h, int(flags)))
 
     def best(self):
         idx = ctypes.c_int64(-1)

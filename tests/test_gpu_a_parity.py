@@ -742,3 +742,103 @@ def test_ei_path_factor_through_the_data_flow_launch(eng, N, D, H, per_sec):
             assert msgs[0] == msgs[1] and "positive definite" in msgs[0]
     finally:
         eng.set_option("ei_flow", -1)
+
+
+# ---- the fused small-N EI pass (fused_kernels.hip: K* -> beta -> EI in one kernel, N <= 128) ------------------------
+@pytest.mark.parametrize("N,M,D,H,seed", [(20, 1000, 2, 10, 901), (64, 5000, 8, 10, 902), (128, 20000, 8, 10, 903),
+                                          (97, 3001, 5, 7, 904), (3, 200, 1, 2, 905), (128, 4099, 33, 3, 906),
+                                          (17, 777, 16, 4, 907)])
+def test_fused_small_n_equals_the_general_path_and_the_oracle(eng, N, M, D, H, seed):
+    """N <= 128 (where Spearmint lives: tens of observations, S/main.py:83-85): the one-kernel EI pass gives, bit for
+    bit, what the three-stage path (k_cov -> k_predict_gemm_tri -> k_ei_finalize) gives -- EI per draw, predictive
+    moments, mean, winner -- and both match the oracle to the path's tolerance."""
+    comp, cand, vals, hypers = synthetic_problem(N, M, D, H, seed)
+    try:
+        eng.set_option("ei_fused", 0)
+        a = eng.ei_grid(comp, vals, cand, hypers, want_draws=True, flags=2)   # SPX_FLAG_KEEP_MOMENTS
+        ma = [eng.get_moments(h) for h in range(H)]
+        eng.set_option("ei_fused", 1)
+        b = eng.ei_grid(comp, vals, cand, hypers, want_draws=True, flags=2)
+        mb = [eng.get_moments(h) for h in range(H)]
+    finally:
+        eng.set_option("ei_fused", -1)
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    for (m0, v0), (m1, v1) in zip(ma, mb):
+        assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+    ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert_ei_close(b[3], ref)
+    assert b[0] == orc.choose(ref)
+
+
+@pytest.mark.parametrize("kname", ["Matern32", "ARDSE"])
+def test_fused_small_n_other_covariances_and_per_second(eng, kname):
+    comp, cand, vals, hypers, ld, th = synthetic_problem(90, 6000, 6, 5, 911, per_sec=True)
+    try:
+        eng.set_covar(kname)
+        eng.set_option("ei_fused", 0)
+        a = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        pa = eng.ei_per_sec_grid(comp, vals, ld, cand, hypers, th, want_draws=True)
+        eng.set_option("ei_fused", 1)
+        b = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        pb = eng.ei_per_sec_grid(comp, vals, ld, cand, hypers, th, want_draws=True)
+    finally:
+        eng.set_option("ei_fused", -1)
+        eng.set_covar("Matern52")
+    assert a[0] == b[0] and np.array_equal(a[3], b[3])
+    assert pa[0] == pb[0] and np.array_equal(pa[3], pb[3]) and np.array_equal(pa[2], pb[2])
+    with orc.covar(kname):
+        ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert_ei_close(b[3], ref)
+
+
+def test_fused_small_n_nan_candidate_and_chunks(eng):
+    """A NaN candidate wins like numpy's argmax in the fused pass too; chunked candidates (a small staging budget) do not
+    change a bit."""
+    comp, cand, vals, hypers = synthetic_problem(50, 9000, 4, 6, 921)
+    one = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    try:
+        eng.set_option("kstar_budget_bytes", 8 * 128 * 2048)      # chunks of 2048 candidates
+        many = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    finally:
+        eng.set_option("kstar_budget_bytes", 0)
+    assert one[0] == many[0] and np.array_equal(one[3], many[3])
+    bad = cand.copy(); bad[4321, 2] = np.nan
+    idx, val, mean, draws = eng.ei_grid(comp, vals, bad, hypers, want_draws=True)
+    assert idx == 4321 and np.isnan(val) and np.all(np.isnan(draws[4321]))
+    keep = np.ones(len(cand), bool); keep[4321] = False
+    assert np.array_equal(draws[keep], one[3][keep])
+
+
+@pytest.mark.parametrize("N,M,D,H,per_sec", [(40, 3000, 3, 5, False), (128, 9000, 8, 10, True), (700, 5000, 6, 4, False)])
+def test_ei_step_is_factor_plus_run_with_one_synchronisation(eng, N, M, D, H, per_sec):
+    """spx_ei_step (what bench.py times and spx_ei_grid runs): the same results as spx_factor + spx_ei_run, the not-PD
+    error reported as spx_factor reports it (LinAlgError, draw / pivot), and the handle fine afterwards."""
+    from numpy.linalg import LinAlgError
+    comp, cand, vals, hypers, ld, th = synthetic_problem(N, M, D, H, 940 + N, per_sec=True)
+    fl = 1 if per_sec else 0
+    eng.set_observations(comp, vals); eng.set_candidates(cand); eng.set_hypers(hypers)
+    if per_sec:
+        eng.set_time_model(ld, th)
+    eng.factor(); eng.ei_run(fl)
+    two = (eng.best(), eng.ei_draws(), eng.ei_mean())
+    eng.set_hypers(hypers)
+    if per_sec:
+        eng.set_time_model(ld, th)
+    eng.ei_step(fl)
+    one = (eng.best(), eng.ei_draws(), eng.ei_mean())
+    assert one[0] == two[0] and np.array_equal(one[1], two[1]) and np.array_equal(one[2], two[2])
+    bad = hypers.copy(); bad[H // 2, 2] = -1.0                 # a negative amplitude: not positive definite
+    eng.set_hypers(bad)
+    if per_sec:
+        eng.set_time_model(ld, th)                             # (spx_set_hypers drops the time model)
+    with pytest.raises(LinAlgError):
+        eng.ei_step(fl)
+    assert eng.not_pd_info()[0] == H // 2
+    with pytest.raises(ValueError):
+        eng.best()                                             # no results after a failed step
+    eng.set_hypers(hypers)
+    if per_sec:
+        eng.set_time_model(ld, th)
+    eng.ei_step(fl)
+    assert eng.best() == two[0] and np.array_equal(eng.ei_draws(), two[1])
