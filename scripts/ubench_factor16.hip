@@ -60,6 +60,147 @@ __device__ __forceinline__ void factor16(d4& C, d4& X, d4& U, int lane, int& bad
     }
 }
 
+// row of 16 lanes q -> row q + 1 for q = 0, 2 (v_permlane16_swap_b32: odd rows of the first operand <-> even rows of the second)
+__device__ __forceinline__ double from_even_row(double v)
+{
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]);
+}
+
+// V5: TWO pivots per MFMA (k-slots j & 3 and (j & 3) + 1): every value is formed by the same operations as in V0 -- the
+// second pivot's row is brought up to date by one explicit fma (what the rank-1 MFMA of the first pivot would have done
+// to it) -- so the factor and the inverse are the same bits IF the MFMA adds its k-slots in ascending order, one rounded
+// fma each (checked below against V0).
+template <>
+__device__ __forceinline__ void factor16<5>(d4& C, d4& Xout, d4& U, int lane, int& bad)
+{
+    const int c = lane & 15, q = lane >> 4;
+    d4 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { X[r] = (q + 4 * r == c) ? 1.0 : 0.0; U[r] = 0.0; Xout[r] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const int qa = j & 3, rj = j >> 2;
+        const bool ga = (q == qa), gb = (q == qa + 1);
+        double d0 = readlane_f64(C[rj], j + 16 * qa);
+        const double e = readlane_f64(C[rj], j + 1 + 16 * qa);
+        const double d1 = readlane_f64(C[rj], j + 1 + 16 * (qa + 1));
+        if (!(d0 > 0.0)) { if (!bad) bad = j + 1; d0 = 1.0; }
+        const double y0 = __builtin_amdgcn_rsq(d0);
+        const double e0 = fma(-d0 * y0, y0, 1.0);
+        const double rinv0 = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+        const double l10 = e * rinv0;
+        double d1p = fma(-l10, l10, d1);
+        if (!(d1p > 0.0)) { if (!bad) bad = j + 2; d1p = 1.0; }
+        const double y1 = __builtin_amdgcn_rsq(d1p);
+        const double e1 = fma(-d1p * y1, y1, 1.0);
+        const double rinv1 = fma(y1 * e1, fma(0.375, e1, 0.5), y1);
+        const double l0 = C[rj] * rinv0;                 // (meaningful in group qa: column j of L)
+        const double x0 = X[rj] * rinv0;                 // (group qa: row j of the inverse, final)
+        const double l0n = from_even_row(l0), x0n = from_even_row(x0);
+        const double l1 = fma(-l10, l0n, C[rj]) * rinv1; // (group qa + 1: column j + 1 of L)
+        const double x1 = fma(-l10, x0n, X[rj]) * rinv1;
+        const double bC = ga ? l0 : (gb ? l1 : 0.0);
+        C = MFMA_F64(-bC, bC, C);
+        const double bX = ga ? x0 : (gb ? x1 : 0.0);
+        const double aX = (ga && c > j) ? -l0 : ((gb && c > j + 1) ? -l1 : 0.0);
+        X = MFMA_F64(aX, bX, X);
+        Xout[rj] = ga ? x0 : (gb ? x1 : Xout[rj]);
+        double sd0 = d0 * rinv0;
+        sd0 = fma(fma(-sd0, sd0, d0), 0.5 * rinv0, sd0);
+        double sd1 = d1p * rinv1;
+        sd1 = fma(fma(-sd1, sd1, d1p), 0.5 * rinv1, sd1);
+        const double keep0 = (c == j) ? sd0 : ((c > j) ? l0 : 0.0);
+        const double keep1 = (c == j + 1) ? sd1 : ((c > j + 1) ? l1 : 0.0);
+        U[rj] = ga ? keep0 : (gb ? keep1 : U[rj]);
+    }
+}
+
+// all-gather over the four 16-lane rows: v of row a -> out[a] in every row (one v_permlane16_swap + two v_permlane32_swap per dword)
+__device__ __forceinline__ void gather_rows(double v, double (&out)[4])
+{
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // a[0] = rows (0,0,2,2), a[1] = rows (1,1,3,3)
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const auto a0 = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);   // [0] = row 0 everywhere, [1] = row 2
+    const auto a1 = __builtin_amdgcn_permlane32_swap(a[1], a[1], false, false);   // [0] = row 1, [1] = row 3
+    const auto b0 = __builtin_amdgcn_permlane32_swap(b[0], b[0], false, false);
+    const auto b1 = __builtin_amdgcn_permlane32_swap(b[1], b[1], false, false);
+    out[0] = __hiloint2double(b0[0], a0[0]);
+    out[1] = __hiloint2double(b1[0], a1[0]);
+    out[2] = __hiloint2double(b0[1], a0[1]);
+    out[3] = __hiloint2double(b1[1], a1[1]);
+}
+__device__ __forceinline__ double rsq_refined(double d)
+{
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e0 = fma(-d * y0, y0, 1.0);
+    return fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+}
+__device__ __forceinline__ double sqrt_from(double d, double rinv)
+{
+    double sd = d * rinv;
+    return fma(fma(-sd, sd, d), 0.5 * rinv, sd);
+}
+
+// V6: FOUR pivots per pair of MFMAs (all k-slots).  The four rows j .. j + 3 of the block sit in the four lane rows of one
+// register; an all-gather gives every lane the four entries of ITS column, the 4x4 pivot block comes by v_readlane, and
+// every lane runs the little recurrence for its column -- each value by the operations the one-pivot form applies to it.
+template <>
+__device__ __forceinline__ void factor16<6>(d4& C, d4& Xout, d4& U, int lane, int& bad)
+{
+    const int c = lane & 15, q = lane >> 4;
+    d4 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { X[r] = (q + 4 * r == c) ? 1.0 : 0.0; U[r] = 0.0; Xout[r] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+        const int rj = j >> 2;
+        // the 4x4 pivot block (lower triangle), before any update of this round
+        double d00 = readlane_f64(C[rj], j + 0 + 16 * 0);
+        const double d10 = readlane_f64(C[rj], j + 0 + 16 * 1), d11 = readlane_f64(C[rj], j + 1 + 16 * 1);
+        const double d20 = readlane_f64(C[rj], j + 0 + 16 * 2), d21 = readlane_f64(C[rj], j + 1 + 16 * 2), d22 = readlane_f64(C[rj], j + 2 + 16 * 2);
+        const double d30 = readlane_f64(C[rj], j + 0 + 16 * 3), d31 = readlane_f64(C[rj], j + 1 + 16 * 3), d32 = readlane_f64(C[rj], j + 2 + 16 * 3),
+                     d33 = readlane_f64(C[rj], j + 3 + 16 * 3);
+        double cc[4], xx[4];
+        gather_rows(C[rj], cc);
+        gather_rows(X[rj], xx);
+        if (!(d00 > 0.0)) { if (!bad) bad = j + 1; d00 = 1.0; }
+        const double r0 = rsq_refined(d00);
+        const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+        double p1 = fma(-l10, l10, d11);
+        if (!(p1 > 0.0)) { if (!bad) bad = j + 2; p1 = 1.0; }
+        const double r1 = rsq_refined(p1);
+        const double l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
+        double p2 = fma(-l21, l21, fma(-l20, l20, d22));
+        if (!(p2 > 0.0)) { if (!bad) bad = j + 3; p2 = 1.0; }
+        const double r2 = rsq_refined(p2);
+        const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
+        double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+        if (!(p3 > 0.0)) { if (!bad) bad = j + 4; p3 = 1.0; }
+        const double r3 = rsq_refined(p3);
+        // this lane's column of L (entries j .. j + 3 of row c of L ... as columns l_a[c]) and of the inverse's rows
+        const double l0 = cc[0] * r0;
+        const double l1 = fma(-l10, l0, cc[1]) * r1;
+        const double l2 = fma(-l21, l1, fma(-l20, l0, cc[2])) * r2;
+        const double l3 = fma(-l32, l2, fma(-l31, l1, fma(-l30, l0, cc[3]))) * r3;
+        const double x0 = xx[0] * r0;
+        const double x1 = fma(-l10, x0, xx[1]) * r1;
+        const double x2 = fma(-l21, x1, fma(-l20, x0, xx[2])) * r2;
+        const double x3 = fma(-l32, x2, fma(-l31, x1, fma(-l30, x0, xx[3]))) * r3;
+        const double lq = (q == 0) ? l0 : (q == 1) ? l1 : (q == 2) ? l2 : l3;
+        const double xq = (q == 0) ? x0 : (q == 1) ? x1 : (q == 2) ? x2 : x3;
+        C = MFMA_F64(-lq, lq, C);
+        const double aX = (c > j + q) ? -lq : 0.0;
+        X = MFMA_F64(aX, xq, X);
+        Xout[rj] = xq;
+        const double sdq = (q == 0) ? sqrt_from(d00, r0) : (q == 1) ? sqrt_from(p1, r1) : (q == 2) ? sqrt_from(p2, r2) : sqrt_from(p3, r3);
+        U[rj] = (c == j + q) ? sdq : ((c > j + q) ? lq : 0.0);
+    }
+}
+
 template <int V>
 __global__ void bench(const double* S, double* out, long long* cyc, int reps)
 {
@@ -85,6 +226,7 @@ __global__ void bench(const double* S, double* out, long long* cyc, int reps)
     if (lane == 0) out[512] = acc + bad;
 }
 
+static double g_ref[513];
 template <int V>
 void run(const double* dS, double* dOut, long long* dCyc, const double* hS, const char* name)
 {
@@ -102,8 +244,16 @@ void run(const double* dS, double* dOut, long long* dCyc, const double* hS, cons
         for (int k = 0; k < 16; ++k) s += out[(k * 16 + i) * 2] * out[(k * 16 + j) * 2];
         err = fmax(err, fabs(s - hS[i * 16 + j]));
     }
-    printf("%-44s %7.1f cycles / 16x16 block  = %5.1f / pivot   |U^T U - S| = %.2e\n", name, (double)cyc / reps,
-           (double)cyc / reps / 16, err);
+    // against V0, bit for bit: U (all of it: zeros below the diagonal) and the lower triangle of X = L^-1 (out[(row * 16 + col) * 2 + {0, 1}])
+    if (V == 0) for (int i = 0; i < 512; ++i) g_ref[i] = out[i];
+    int ndiff = 0;
+    for (int row = 0; row < 16; ++row)
+        for (int col = 0; col < 16; ++col) {
+            if (out[(row * 16 + col) * 2] != g_ref[(row * 16 + col) * 2]) ++ndiff;
+            if (col <= row && out[(row * 16 + col) * 2 + 1] != g_ref[(row * 16 + col) * 2 + 1]) ++ndiff;
+        }
+    printf("%-44s %7.1f cycles / 16x16 block  = %5.1f / pivot   |U^T U - S| = %.2e   values of U / tril(X) differing from V0: %d\n", name,
+           (double)cyc / reps, (double)cyc / reps / 16, err, ndiff);
 }
 
 int main()
@@ -124,5 +274,7 @@ int main()
     run<2>(dS, dOut, dCyc, hS, "V2 factor + inverse, no select before rsq");
     run<3>(dS, dOut, dCyc, hS, "V3 = V2 with mask multipliers");
     run<4>(dS, dOut, dCyc, hS, "V4 factor only, raw rsq (chain floor probe)");
+    run<5>(dS, dOut, dCyc, hS, "V5 factor + inverse, TWO pivots per MFMA");
+    run<6>(dS, dOut, dCyc, hS, "V6 factor + inverse, FOUR pivots per MFMA");
     return 0;
 }

@@ -114,6 +114,22 @@ __device__ __forceinline__ void mma_tile_64(const double* A_lds, const double* B
 // mailbox, per pivot or per four pivots, the inverse wave spinning on a sequence word -- was measured:
 // the factor wave alone runs 300 cycles per pivot next to its busy neighbours, and the inverse wave
 // trails by ~1.1k cycles, 5.9k per sub-block either way against 5.85k for this single-wave form.)
+// Round 4: TWO pivots per pair of MFMAs.  Pivots j and j + 1 (j even) live in the neighbouring k-slots j & 3 and (j & 3) + 1
+// of the same register, so one v_mfma_f64_16x16x4 applies both rank-1 updates.  What the second pivot needs of the first
+// one's update -- its own row, C[j+1][:] - l_{j+1,j} l_j^T -- is one explicit fma per lane on the column l_j brought over
+// from the neighbouring lane row (v_permlane16_swap_b32: rows 0 -> 1, 2 -> 3), and the pivot itself is
+// fma(-l_{j+1,j}, l_{j+1,j}, C[j+1][j+1]) on three v_readlane values.  The matrix pipe adds its k-slots in ascending
+// order, one rounded fma each, so every value is formed by the same operations as with one MFMA per pivot: the factor and
+// the inverse are the same bits (scripts/ubench_factor16.hip compares the two forms value by value), 287 cycles per pivot
+// instead of 331 -- each MFMA a pivot issues costs ~100 cycles of the in-order wave, and there are now half as many.
+// row of 16 lanes q -> row q + 1 for q = 0, 2
+__device__ __forceinline__ double from_even_row(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
 __device__ __forceinline__ void factor16_mfma(d4& C, d4& Xo, d4& U, int lane, int& bad, int pivot_base)
 {
     const int c = lane & 15, q = lane >> 4;
@@ -125,32 +141,49 @@ __device__ __forceinline__ void factor16_mfma(d4& C, d4& Xo, d4& U, int lane, in
         U[r] = 0.0;
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int kq = j & 3, rj = j >> 2;
-        double d = readlane_f64(C[rj], j + 16 * kq);
-        if (!(d > 0.0)) {  // also catches NaN, like LAPACK dpotrf's (ajj <= 0 || isnan)
+    for (int j = 0; j < 16; j += 2) {
+        const int qa = j & 3, rj = j >> 2;
+        const bool ga = (q == qa), gb = (q == qa + 1);
+        double d0 = readlane_f64(C[rj], j + 16 * qa);
+        const double e = readlane_f64(C[rj], j + 1 + 16 * qa);            // C[j][j+1]
+        const double d1 = readlane_f64(C[rj], j + 1 + 16 * (qa + 1));
+        if (!(d0 > 0.0)) {  // also catches NaN, like LAPACK dpotrf's (ajj <= 0 || isnan)
             if (!bad) bad = pivot_base + j + 1;
-            d = 1.0;
+            d0 = 1.0;
         }
-        const double y0 = __builtin_amdgcn_rsq(d);
-        const double e0 = fma(-d * y0, y0, 1.0);
-        const double rinv = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
-        const bool grp = (q == kq);
-        const double lcol = C[rj] * rinv;
-        const double b = grp ? lcol : 0.0;
-        const double xs = X[rj] * rinv;
-        const double bX = grp ? xs : 0.0;
-        const double aX = (grp && c > j) ? -lcol : 0.0;
-        C = MFMA_F64(-b, b, C);
+        const double y0 = __builtin_amdgcn_rsq(d0);
+        const double e0 = fma(-d0 * y0, y0, 1.0);
+        const double rinv0 = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+        const double l10 = e * rinv0;                                    // L[j+1][j]
+        double d1p = fma(-l10, l10, d1);                                 // the pivot j + 1 after pivot j's update
+        if (!(d1p > 0.0)) {
+            if (!bad) bad = pivot_base + j + 2;
+            d1p = 1.0;
+        }
+        const double y1 = __builtin_amdgcn_rsq(d1p);
+        const double e1 = fma(-d1p * y1, y1, 1.0);
+        const double rinv1 = fma(y1 * e1, fma(0.375, e1, 0.5), y1);
+        const double l0 = C[rj] * rinv0;                                 // lane row qa: column j of L
+        const double x0 = X[rj] * rinv0;                                 // lane row qa: row j of the inverse (final)
+        const double l0n = from_even_row(l0), x0n = from_even_row(x0);
+        const double l1 = fma(-l10, l0n, C[rj]) * rinv1;                 // lane row qa + 1: column j + 1 of L
+        const double x1 = fma(-l10, x0n, X[rj]) * rinv1;                 // lane row qa + 1: row j + 1 of the inverse
+        const double bC = ga ? l0 : (gb ? l1 : 0.0);
+        C = MFMA_F64(-bC, bC, C);
+        const double bX = ga ? x0 : (gb ? x1 : 0.0);
+        const double aX = (ga && c > j) ? -l0 : ((gb && c > j + 1) ? -l1 : 0.0);
         X = MFMA_F64(aX, bX, X);
-        // row j of X is final: it is collected in Xo, not written back into the accumulator (a VALU write to an
-        // MFMA destination right behind the MFMA stalls the in-order wave: 328 -> 316 cycles per pivot)
-        Xo[rj] = grp ? xs : Xo[rj];
-        // the diagonal entry sqrt(d) to ~0.5 ulp (off the critical path)
-        double sd = d * rinv;
-        sd = fma(fma(-sd, sd, d), 0.5 * rinv, sd);
-        const double keep = (c == j) ? sd : ((c > j) ? lcol : 0.0);
-        U[rj] = grp ? keep : U[rj];
+        // rows j, j + 1 of X are final: collected in Xo, not written back into the accumulator (a VALU write to an MFMA
+        // destination right behind the MFMA stalls the in-order wave)
+        Xo[rj] = ga ? x0 : (gb ? x1 : Xo[rj]);
+        // the diagonal entries sqrt(d) to ~0.5 ulp (off the critical path)
+        double sd0 = d0 * rinv0;
+        sd0 = fma(fma(-sd0, sd0, d0), 0.5 * rinv0, sd0);
+        double sd1 = d1p * rinv1;
+        sd1 = fma(fma(-sd1, sd1, d1p), 0.5 * rinv1, sd1);
+        const double keep0 = (c == j) ? sd0 : ((c > j) ? l0 : 0.0);
+        const double keep1 = (c == j + 1) ? sd1 : ((c > j + 1) ? l1 : 0.0);
+        U[rj] = ga ? keep0 : (gb ? keep1 : U[rj]);
     }
 }
 
