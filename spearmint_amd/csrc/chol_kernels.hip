@@ -1535,6 +1535,12 @@ __global__ __launch_bounds__(256, 2) void k_trinv(const double* __restrict__ Lm,
         const int n = idx >> 6, i = idx & 63;
         Wh[(j0 + n) * Np + j0 + i] = Dh[(size_t)jb * NB * NB + i * NB + n];
     }
+    // W is lower triangular: WT[j0 + n][i] = 0 for i < j0 -- written here, by the workgroup that owns these rows, instead
+    // of a memset of the whole [nh][Np][Np] buffer before the launch (twice the bytes, and one more stream operation)
+    for (int idx = threadIdx.x; idx < NB * (int)(j0 / 2); idx += 256) {
+        const int n = idx / (int)(j0 / 2), i2 = idx - n * (int)(j0 / 2);
+        *reinterpret_cast<d2*>(Wh + (j0 + n) * Np + 2 * i2) = (d2){0.0, 0.0};
+    }
     for (int ib = jb + 1; ib < nblk; ++ib) {
         const size_t i0 = (size_t)ib * NB;
         d4 acc[4];
@@ -1618,7 +1624,19 @@ __global__ __launch_bounds__(256) void k_gamma(const double* __restrict__ WT, si
         r[threadIdx.x] = (jj < N) ? (vh[jj] - mean) : 0.0;
         __syncthreads();
         const int jn = (i < Np) ? min(256, i - jb + 1) : 0;
-        for (int t = 0; t < jn; ++t) acc += Wh[(size_t)(jb + t) * Np + i] * r[t];
+        // the sum runs in the order j = 0, 1, 2, ... (one fma each: these bits are part of every EI value), but its loads
+        // need not: 16 of them are in flight at a time -- with the compiler's 4 the launch was one memory round trip per
+        // four rows (11 us at N = 128, 21 us at N = 256, one launch per factorisation)
+        const double* wp = Wh + (size_t)jb * Np + i;
+        int t = 0;
+        for (; t + 16 <= jn; t += 16) {
+            double w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = wp[(size_t)(t + u) * Np];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fma(w[u], r[t + u], acc);
+        }
+        for (; t < jn; ++t) acc = fma(wp[(size_t)t * Np], r[t], acc);
     }
     if (i < Np) gamma[(size_t)b * Np + i] = acc;
 }

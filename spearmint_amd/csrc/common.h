@@ -35,7 +35,8 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp,
                        const double* ls /*[nh][ls_stride]*/, int ls_stride, int nh, double factor,
                        double* xs /*[nh][n_pad][Dp]*/, double* sumsq /*[nh][n_pad]*/,
-                       double* xs2 = nullptr /*optional: 2 * xs, same launch*/);
+                       double* xs2 = nullptr /*optional: 2 * xs, same launch*/,
+                       int* zero_ints = nullptr /*optional: n_zero ints cleared by the same launch*/, int n_zero = 0);
 void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const double* X2s,
                      const double* htab, double* K, int N, int Np, int Dp, int nh, bool tiled = false,
                      int kind = SPX_COV_MATERN52);

@@ -30,9 +30,12 @@ template <int ROWS>
 __global__ __launch_bounds__(256) void k_scale_rows(
     const double* __restrict__ x, int64_t n, int64_t n_pad, int D, int Dp,
     const double* __restrict__ ls, int ls_stride, double factor,
-    double* __restrict__ xs, double* __restrict__ sumsq, double* __restrict__ xs2)
+    double* __restrict__ xs, double* __restrict__ sumsq, double* __restrict__ xs2, int* __restrict__ zero_ints, int n_zero)
 {
 #pragma clang fp contract(off)
+    // (the first kernel of a factorisation also clears its not-PD flags: one stream operation fewer per call)
+    if (zero_ints && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int e = threadIdx.x; e < n_zero; e += 256) zero_ints[e] = 0;
     // ROWS rows per workgroup, staged through LDS so that both the read of x (rows of D doubles)
     // and the write of xs (rows of Dp doubles) are contiguous across the wave; each thread then
     // owns one row and accumulates its squared norm left to right.
@@ -79,14 +82,14 @@ __global__ __launch_bounds__(256) void k_scale_rows(
 
 void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp,
                        const double* ls, int ls_stride, int nh, double factor,
-                       double* xs, double* sumsq, double* xs2)
+                       double* xs, double* sumsq, double* xs2, int* zero_ints, int n_zero)
 {
     if (((n_pad + 255) / 256) * nh < 512) {
         dim3 grid((unsigned)((n_pad + 63) / 64), nh);
-        hipLaunchKernelGGL(k_scale_rows<64>, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride, factor, xs, sumsq, xs2);
+        hipLaunchKernelGGL(k_scale_rows<64>, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride, factor, xs, sumsq, xs2, zero_ints, n_zero);
     } else {
         dim3 grid((unsigned)((n_pad + 255) / 256), nh);
-        hipLaunchKernelGGL(k_scale_rows<256>, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride, factor, xs, sumsq, xs2);
+        hipLaunchKernelGGL(k_scale_rows<256>, grid, dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride, factor, xs, sumsq, xs2, zero_ints, n_zero);
     }
 }
 

@@ -354,12 +354,13 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // the log-likelihood path zeroes info (and the hand-off flags) in its right-hand-side kernel: two stream operations
     // fewer per call
     const bool zero_in_kernel = lean && nh <= 32;
-    if (!zero_in_kernel) HIPCHK(hipMemsetAsync(h->info.p, 0, (size_t)nh * sizeof(int), s));
-    if (!lean) HIPCHK(hipMemsetAsync(h->WT.p, 0, nn * 8, s));
+    // (otherwise k_scale_rows, the first kernel below, clears them)
+    // (W^T's zeros above the diagonal blocks are written by k_trinv itself)
 
     const double* ls = h->hyp.d() + 3;
     // x / ls and, in the same launch, the second operand pre-multiplied by 2 (gp.py:50; exact)
-    TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d(), h->X2s.d()));
+    TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d(), h->X2s.d(),
+                                      zero_in_kernel ? nullptr : (int*)h->info.p, nh));
     // The factorisation, blocked with 64x64 tiles; three generations, the same factor bit for bit (every tile receives its
     // update steps in the order 0, 1, 2, ..., through the same MFMA chains, and the diagonal blocks share diag_block):
     //   flow  k_lean_flow: ONE data-flow launch for all block columns of all draws, tile-major storage (the default);
