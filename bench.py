@@ -50,6 +50,7 @@ timed on this host: 20 000 candidates, one warm-up, median of three runs.
 from __future__ import print_function
 
 import argparse
+import subprocess
 import json
 import os
 import sys
@@ -92,8 +93,9 @@ def pmc_traffic(workload):
     """HBM bytes per k_predict_gemm launch from the committed rocprofv3 PMC passes of this
     same command (profiles/r0X_<workload>_rocprof_summary.json, written by
     scripts/pmc_summary.py: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE
-    doubled per the gfx950 correction of MI355X_MICROARCH.md).  None when no profile exists."""
-    for rnd in ("r03", "r02", "r01"):
+    doubled per the gfx950 correction of MI355X_MICROARCH.md).  None when no profile exists.
+    The fallback of live_traffic() below."""
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_rocprof_summary.json" % (rnd, workload))
         try:
             with open(path) as fh:
@@ -103,6 +105,54 @@ def pmc_traffic(workload):
         except Exception:
             continue
     return None, None
+
+
+def live_traffic(workload, timeout_s=240):
+    """`roofline.traffic` measured IN this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one
+    pass -- MI355X_MICROARCH.md, rocprofv3 section; no trace domain beside them) over a one-step child of this very
+    command, counters of the dominant kernel only, per-launch mean, FETCH_SIZE doubled (the guide's gfx950 correction),
+    WRITE_SIZE as it is.  (bytes, source text), or (None, reason) when rocprofv3 is missing or a pass fails -- the caller
+    then falls back to the committed profile."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    got = {}
+    work = tempfile.mkdtemp(prefix="spx_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "0",
+             "--no-cpu-baseline", "--skip-extras", "--no-live-traffic", "--event-steps", "0"]
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-include-regex", "k_predict_gemm", "--output-format", "csv", "-d", out,
+                   "--"] + child
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, 9)          # the group this call started, nothing else
+                proc.wait()
+                return None, "rocprofv3 --pmc %s timed out" % counter
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            vals = []
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and "k_predict_gemm" in r["Kernel_Name"]:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, "rocprofv3 --pmc %s produced no rows (rc %s)" % (counter, proc.returncode)
+            got[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    traffic = (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0
+    return traffic, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over a one-step child of this "
+                     "command, %d + %d k_predict_gemm launches, per-launch mean, FETCH_SIZE x 2 (gfx950 correction), KiB -> bytes"
+                     % (got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]))
 
 
 def _reference_chooser(D, H):
@@ -318,6 +368,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-candidates", type=int, default=20000)
     ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic in this run (use the committed profile)")
     ap.add_argument("--skip-extras", action="store_true", help="do not time the strong-scaling c4 / c5 sub-records")
     ap.add_argument("--extra-steps", type=int, default=2, help="timed steps of each strong-scaling sub-record (after 1 warm-up)")
     ap.add_argument("--hyper-shards", type=int, default=1,
@@ -468,7 +520,14 @@ def main():
         avg_s = gemm_ms / gemm_n * 1e-3
         evals_per_launch = evals_per_step * ev_steps / gemm_n
         achieved = flops_per_eval * evals_per_launch / avg_s / 1e12
-        traffic, traffic_src = pmc_traffic(args.workload) if world == 1 else (None, None)
+        traffic, traffic_src, traffic_note = None, None, None
+        if world == 1:
+            if not args.no_live_traffic:
+                traffic, traffic_src = live_traffic(args.workload)
+                if traffic is None:
+                    traffic_note = traffic_src
+            if traffic is None:
+                traffic, traffic_src = pmc_traffic(args.workload)
         roofline = {"bound": "mfma", "kernel": "k_predict_gemm_tri", "achieved": achieved,
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -477,6 +536,13 @@ def main():
                     "flops_per_eval": flops_per_eval, "evals_per_launch": evals_per_launch,
                     "measured_over": "%d steps with per-launch HIP events on the library's stream" % ev_steps,
                     "dtype_peak_source": "AMD MI355X spec: 78.6 TFLOP/s fp64 matrix"}
+        # what one launch has to move at least: its K(X*,X) columns once (8 N bytes per evaluation) + the live half of W
+        Npad = -(-N // 128) * 128
+        roofline["algorithmic_bytes"] = 8.0 * Npad * evals_per_launch + 8.0 * Npad * Npad / 2.0
+        if traffic:
+            roofline["traffic_over_algorithmic"] = traffic / roofline["algorithmic_bytes"]
+        if traffic_note:
+            roofline["traffic_live_failed"] = traffic_note
         # second regime: the HBM-side stages.  K(X*,X) producer: 8 N bytes written per
         # evaluation (the staging buffer the GEMM then reads); EI finalize: the per-row-block partial
         # sums (2 x N/128 x 8 B read) + one EI written per evaluation.
