@@ -44,6 +44,8 @@ static int ensure_init(spx_handle* h)
         for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev_sync[i], hipEventDisableTiming));
         HIPCHK(hipEventCreate(&h->ev_t0));
         HIPCHK(hipEventCreate(&h->ev_t1));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_obs, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_p0, hipEventDisableTiming));
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu > 0) h->n_cu = ncu;
         h->inited = true;
@@ -147,6 +149,8 @@ void spx_destroy(spx_handle* h)
         for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
         (void)hipEventDestroy(h->ev_t0);
         (void)hipEventDestroy(h->ev_t1);
+        (void)hipEventDestroy(h->ev_obs);
+        (void)hipEventDestroy(h->ev_p0);
         (void)hipStreamDestroy(h->stream);
         (void)hipStreamDestroy(h->stream2);
     }
@@ -176,6 +180,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_lazy")) {   // log-likelihood path: trailing updates two steps at a time (1), one (0), by size (-1, default)
         h->lean_lazy = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "step_overlap")) {   // spx_ei_step: candidate scaling + first K(X*,X) on the second stream beside the factorisation (1, default) or behind it (0)
+        h->step_overlap = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
     if (!strcmp(name, "ei_fused")) {       // N <= 128, no fantasies: K* -> beta -> EI of a chunk in one kernel (1, default) or the general three-stage path (0)
@@ -361,6 +369,9 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // x / ls and, in the same launch, the second operand pre-multiplied by 2 (gp.py:50; exact)
     TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d(), h->X2s.d(),
                                       zero_in_kernel ? nullptr : (int*)h->info.p, nh));
+    // (spx_ei_step: the candidate side of the EI pass needs x / ls and the hyper table, not the factor -- it starts here,
+    // on the second stream, beside the factorisation)
+    if (defer_sync && !lean) HIPCHK(hipEventRecord(h->ev_obs, s));
     // The factorisation, blocked with 64x64 tiles; three generations, the same factor bit for bit (every tile receives its
     // update steps in the order 0, 1, 2, ..., through the same MFMA chains, and the diagonal blocks share diag_block):
     //   flow  k_lean_flow: ONE data-flow launch for all block columns of all draws, tile-major storage (the default);
@@ -697,6 +708,14 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     // 178 VGPRs one producer wave fits next to the two GEMM waves of a SIMD.
     // events: [0..1] K* of buffer b ready, [2..3] buffer b consumed, [4..5] chunk parity consumed
     hipStream_t G = h->stream, P = (ns == 2) ? h->stream2 : h->stream;
+    // A step (factor_pending): the factorisation is still running on G -- a chain of small launches that leaves most of the
+    // chip idle -- and the first producer work of the pass (candidate scaling, K(X*,X) of the first group of draws) depends
+    // only on what the factorisation's FIRST kernel wrote.  It goes to the second stream, beside the factorisation
+    // (C2: K(X*,X) of all ten draws, 0.10 ms, hidden behind a 0.17 ms factorisation).  A time model's predicted durations
+    // need alpha: they stay behind the factorisation on G, with the chunk's other-parity scaling buffers to themselves.
+    const bool overlap = factor_pending && ns == 1 && h->step_overlap != 0;
+    hipStream_t P0 = overlap ? h->stream2 : P;
+    if (overlap) HIPCHK(hipStreamWaitEvent(P0, h->ev_obs, 0));
     int item = 0, chunk = 0;
     for (int64_t c0 = 0; c0 < Mp; c0 += Mc, ++chunk) {
         const int mc = (int)std::min<int64_t>(Mc, Mp - c0);       // multiple of 128
@@ -710,16 +729,25 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
         if (ns == 2 && chunk >= 2) HIPCHK(hipStreamWaitEvent(P, h->ev_sync[4 + par], 0));
         if (per_sec) {
             // log-duration GP: predicted duration of every candidate of the chunk, all draws in one launch
-            TIMED_S(ST_SCALE, P, launch_scale_rows(P, xc, nreal, mc, D, Dp, ls + (size_t)H * hs, hs, H, 2.0, Cs, s2));
-            TIMED_S(ST_CROSS_MEAN, P, launch_cross_mean(P, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np, Cs, s2,
+            const bool side = overlap && chunk == 0;         // (a step's first chunk: the objective's scaling runs on P0 meanwhile)
+            hipStream_t T = side ? G : P;
+            double* CsT = side ? h->Cs[par ^ 1].d() : Cs;
+            double* s2T = side ? h->s2[par ^ 1].d() : s2;
+            TIMED_S(ST_SCALE, T, launch_scale_rows(T, xc, nreal, mc, D, Dp, ls + (size_t)H * hs, hs, H, 2.0, CsT, s2T));
+            TIMED_S(ST_CROSS_MEAN, T, launch_cross_mean(T, h->Xs.d() + (size_t)H * Np * Dp, h->s1.d() + (size_t)H * Np, CsT, s2T,
                                                         h->htab.d() + (size_t)H * SPX_HT, h->alpha.d() + (size_t)H * Np, tm,
                                                         (int)N, Np, mc, Dp, H, dev_kind(h)));
+            if (keep_mom)   // predicted durations [H][mc] -> [H][Mp] for spx_get_time_mean
+                HIPCHK(hipMemcpy2DAsync(h->mom_t.d() + c0, (size_t)Mp * 8, tm, (size_t)mc * 8,
+                                        (size_t)std::min<int64_t>(mc, Mp - c0) * 8, (size_t)H, hipMemcpyDeviceToDevice, T));
         }
-        if (per_sec && keep_mom)   // predicted durations [H][mc] -> [H][Mp] for spx_get_time_mean
-            HIPCHK(hipMemcpy2DAsync(h->mom_t.d() + c0, (size_t)Mp * 8, tm, (size_t)mc * 8,
-                                    (size_t)std::min<int64_t>(mc, Mp - c0) * 8, (size_t)H, hipMemcpyDeviceToDevice, P));
         // 2 * cand / ls and |cand / ls|^2 for every draw (one launch per chunk)
-        TIMED_S(ST_SCALE, P, launch_scale_rows(P, xc, nreal, mc, D, Dp, ls, hs, H, 2.0, Cs, s2));
+        hipStream_t Pc = (chunk == 0) ? P0 : P;       // (the first chunk's producer work of a step: beside the factorisation)
+        TIMED_S(ST_SCALE, Pc, launch_scale_rows(Pc, xc, nreal, mc, D, Dp, ls, hs, H, 2.0, Cs, s2));
+        if (fused && Pc != G) {
+            HIPCHK(hipEventRecord(h->ev_p0, Pc));
+            HIPCHK(hipStreamWaitEvent(G, h->ev_p0, 0));
+        }
         if (fused)
             TIMED_S(ST_PREDICT_GEMM, G, launch_ei_fused128(G, dev_kind(h), h->WT.d(), h->gamma.d(), h->Xs.d(), h->s1.d(), Cs, s2,
                                                            h->htab.d(), tm, h->best, h->ei_draw.d(), keep_mom ? h->mom_m.d() : nullptr,
@@ -728,12 +756,16 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
             const int nhb = std::min(Hb, H - h0);
             const int k = (ns == 2) ? (item & 1) : 0;
             if (ns == 2 && item >= 2) HIPCHK(hipStreamWaitEvent(P, h->ev_sync[2 + k], 0));   // buffer k consumed
-            TIMED_S(ST_COV_CROSS, P, launch_cov_cross(P, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
+            hipStream_t Pi = (item == 0) ? Pc : P;
+            TIMED_S(ST_COV_CROSS, Pi, launch_cov_cross(Pi, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
                                                       Cs + (size_t)h0 * mc * Dp, s2 + (size_t)h0 * mc,
                                                       h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb, dev_kind(h)));
             if (ns == 2) {
                 HIPCHK(hipEventRecord(h->ev_sync[k], P));
                 HIPCHK(hipStreamWaitEvent(G, h->ev_sync[k], 0));
+            } else if (Pi != G) {
+                HIPCHK(hipEventRecord(h->ev_p0, Pi));
+                HIPCHK(hipStreamWaitEvent(G, h->ev_p0, 0));
             }
             // with fantasies (Hb = 1) the launch's partial sums are consumed right away and sit at draw 0
             TIMED_S(ST_PREDICT_GEMM, G, launch_predict_gemm(G, h->gemm_variant, h->WT.d() + (size_t)h0 * nn, h->Kst[k].d(),

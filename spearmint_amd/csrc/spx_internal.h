@@ -84,6 +84,7 @@ struct spx_handle {
                                      // work item is generated (VALU) while the GEMM of the current one runs (MFMA)
     hipEvent_t ev_sync[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // whole-stage timers (factor / ei_run)
+    hipEvent_t ev_obs = nullptr, ev_p0 = nullptr;  // spx_ei_step: observations scaled (stream) / first K(X*,X) ready (stream2)
 
     int64_t N = 0, M = 0, index_base = 0;
     int D = 0, Dp = 0, Np = 0, H = 0;
@@ -128,6 +129,7 @@ struct spx_handle {
     DevBuf ps_flags;                                                // k_lean_step_ps: progress of every diagonal block, [H][nblk]
     int lean_flow = -1;                                             // option "lean_flow": whole factorisation in one launch (k_lean_flow)
     int ei_fused = -1;                                              // option "ei_fused": N <= 128 without fantasies: the EI pass of a chunk as ONE kernel (k_ei_fused128) 1 / 0 / -1 = default (on)
+    int step_overlap = -1;                                          // option "step_overlap": spx_ei_step starts the candidate side beside the factorisation 1 / 0 / -1 = default (on)
     int n_cu = 256;                                                 // compute units of the device (ensure_init)
     int ei_flow = -1;                                               // option "ei_flow": spx_factor through k_lean_flow 1 / 0 / -1 = default (on)
     bool factor_tiled = false;                                      // the EI path's factor is tile-major (k_lean_flow made it)
