@@ -228,6 +228,13 @@ int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot);
  * executed with SPX_FLAG_TIMING.  Fills up to n entries of ms[] / launches[]
  * in the order of spx_timing_name(i); returns the number of stages.            */
 int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n);
+/* Counters a caller can poll instead of reading stderr (single-GPU handles):
+ *   "flow_fallbacks"   in-launch hand-off time-outs of the one-launch factorisation (k_lean_flow) so far; after the
+ *                      first one the handle factors with one launch per block column (same bits) -- never seen on a
+ *                      healthy device, bounded spins make it an error path instead of a hang;
+ *   "flow_enabled"     1 while the one-launch factorisation is in use;   "n_cu"  compute units of the device;
+ *   "last_step_fused"  1 if the last EI pass ran as the one-kernel small-N form (N <= 128, no fantasies).        */
+int spx_get_stat(spx_handle* h, const char* name, int64_t* value);
 const char* spx_timing_name(int i);
 /* The correlation function of the GP -- the choosers' covar= argument, a function of
  * spearmint/spearmint/gp.py selected by name (GPEIChooser.py:52): option "covar" of a handle.

@@ -133,8 +133,7 @@ class GPEIperSecChooser(GPEIBase):
         eng.set_candidates(cand)
         eng.set_hypers(rows)
         eng.set_time_model(durs, trows)
-        eng.factor()
-        eng.ei_run(FLAG_PER_SEC | FLAG_KEEP_MOMENTS)
+        eng.ei_step(FLAG_PER_SEC | FLAG_KEEP_MOMENTS)      # factor + run, one synchronisation
         time_m = np.stack([eng.get_time_mean(h) for h in range(H)], axis=1)
         # pass 2: EI averaged over fantasies
         _, _, ei = self._ei_with_pending_gpu(comp, pend, cand, vals, rows, randn, True)

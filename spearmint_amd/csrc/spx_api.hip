@@ -516,7 +516,9 @@ int spx_factor(spx_handle* h)
     h->handoff_timeout = false;
     int rc = do_factor(h, false);
     if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {   // as in spx_gp_logprob: never seen; bounded, then the launches
-        fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
+        h->flow_fallbacks += 1;      // queryable: spx_get_stat("flow_fallbacks"); the message goes to stderr once per handle
+        if (h->flow_fallbacks == 1)
+            fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
         h->lean_flow = 0;
         h->handoff_timeout = false;
         rc = do_factor(h, false);
@@ -624,7 +626,9 @@ int spx_ei_step(spx_handle* h, int32_t flags)
     h->S = 0;                      // a new factorisation drops the fantasies (finish_factor), here before the run
     rc = ei_run_impl(h, flags, true);
     if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {   // as in spx_factor: bounded, then the launches
-        fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
+        h->flow_fallbacks += 1;      // queryable: spx_get_stat("flow_fallbacks"); the message goes to stderr once per handle
+        if (h->flow_fallbacks == 1)
+            fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
         h->lean_flow = 0;
         h->handoff_timeout = false;
         rc = spx_factor(h);
@@ -663,6 +667,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     // N <= 128 without fantasies: the whole EI pass of a chunk -- K(X,X*), beta = W K*, the moments, EI -- is one kernel
     // with K* and beta in registers (fused_kernels.hip; option ei_fused); same bits as the three-stage path below
     const bool fused = Np == SPX_PADN && S == 0 && h->ei_fused != 0;
+    h->last_fused = fused;
     const int ns = fused ? 1 : h->nstreams;
     for (int b = 0; b < 2; ++b) {
         // scaled candidates (all draws) and predicted durations are double-buffered by chunk parity,
@@ -978,7 +983,9 @@ int spx_gp_logprob(spx_handle* h, double* out)
     if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {
         // never seen on a healthy device; if the one-launch data flow ever stalls (its spins are bounded), the call is
         // repeated with one launch per block column -- same kernels' arithmetic, same bits -- and the handle stays there
-        fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
+        h->flow_fallbacks += 1;      // queryable: spx_get_stat("flow_fallbacks"); the message goes to stderr once per handle
+        if (h->flow_fallbacks == 1)
+            fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
         h->lean_flow = 0;
         h->handoff_timeout = false;
         rc = gp_logprob_once(h, out);
@@ -1155,6 +1162,18 @@ int spx_ei_grad_batch(spx_handle* h, const double* points, int32_t P, double* ne
 int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* grad)
 {
     return spx_ei_grad_batch(h, point, 1, neg_ei_sum, grad);
+}
+
+int spx_get_stat(spx_handle* h, const char* name, int64_t* value)
+{
+    if (!h || !name || !value) return fail(SPX_ERR_ARG, "spx_get_stat: null");
+    if (h->multi) return fail(SPX_ERR_ARG, "spx_get_stat: ask the per-device handles (single-GPU handles only)");
+    if (!strcmp(name, "flow_fallbacks")) *value = h->flow_fallbacks;          // hand-off time-outs of k_lean_flow so far
+    else if (!strcmp(name, "flow_enabled")) *value = h->lean_flow != 0;       // 0 once a time-out switched the handle to one launch per block column
+    else if (!strcmp(name, "n_cu")) *value = h->n_cu;
+    else if (!strcmp(name, "last_step_fused")) *value = h->last_fused ? 1 : 0; // the last EI pass ran k_ei_fused128
+    else return fail(SPX_ERR_ARG, "spx_get_stat: unknown statistic '%s'", name);
+    return SPX_OK;
 }
 
 int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n)

@@ -129,6 +129,8 @@ struct spx_handle {
     DevBuf ps_flags;                                                // k_lean_step_ps: progress of every diagonal block, [H][nblk]
     int lean_flow = -1;                                             // option "lean_flow": whole factorisation in one launch (k_lean_flow)
     int ei_fused = -1;                                              // option "ei_fused": N <= 128 without fantasies: the EI pass of a chunk as ONE kernel (k_ei_fused128) 1 / 0 / -1 = default (on)
+    int64_t flow_fallbacks = 0;                                     // k_lean_flow hand-off time-outs that sent this handle back to one launch per block column
+    bool last_fused = false;                                        // the last EI pass used k_ei_fused128
     int step_overlap = -1;                                          // option "step_overlap": spx_ei_step starts the candidate side beside the factorisation 1 / 0 / -1 = default (on)
     int n_cu = 256;                                                 // compute units of the device (ensure_init)
     int ei_flow = -1;                                               // option "ei_flow": spx_factor through k_lean_flow 1 / 0 / -1 = default (on)

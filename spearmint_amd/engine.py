@@ -75,6 +75,7 @@ ABI = {
                                       ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_int32, _c_double_p]),
     "spx_not_pd_info": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p]),
     "spx_get_timings": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p, ctypes.c_int]),
+    "spx_get_stat": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "spx_timing_name": (ctypes.c_char_p, [ctypes.c_int]),
     "spx_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
 }
@@ -430,6 +431,12 @@ class Engine(object):
         d = ctypes.c_int32(-1); p = ctypes.c_int32(-1)
         self._check(self._lib.spx_not_pd_info(self._h, ctypes.byref(d), ctypes.byref(p)))
         return int(d.value), int(p.value)
+
+    def stat(self, name):
+        """A counter of the handle: "flow_fallbacks", "flow_enabled", "n_cu", "last_step_fused" (include/spx.h: spx_get_stat)."""
+        v = ctypes.c_int64(0)
+        self._check(self._lib.spx_get_stat(self._h, name.encode("ascii"), ctypes.byref(v)))
+        return int(v.value)
 
     def timings(self):
         """{stage: (ms_total, launches)} accumulated since set_option('timing', 1)."""

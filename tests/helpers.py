@@ -56,6 +56,11 @@ class OracleEngine(object):
     def set_fantasies(self, fant, bests):
         self.fant, self.bests = np.asarray(fant, float), np.asarray(bests, float)
 
+    def ei_step(self, flags=0):
+        self.fant = None            # a new factorisation drops the fantasies, as spx_factor / spx_ei_step do
+        self.factor()
+        self.ei_run(flags)
+
     def ei_run(self, flags=0):
         H = self.hypers.shape[0]
         if self.fant is None:

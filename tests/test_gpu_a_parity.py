@@ -699,6 +699,9 @@ def test_in_launch_handoff_under_concurrent_load(eng):
                 for rep in range(4):
                     eng.set_hypers(hyp)
                     assert np.array_equal(eng.gp_logprob(), ref), (name, N, H, rep)
+        # no hand-off timed out on the way (a time-out would have switched the handle to one launch per block column, silently
+        # but for stderr): the counter a caller can poll says so
+        assert eng.stat("flow_fallbacks") == 0 and eng.stat("flow_enabled") == 1
     finally:
         stop.append(1)
         th.join()
@@ -842,3 +845,14 @@ def test_ei_step_is_factor_plus_run_with_one_synchronisation(eng, N, M, D, H, pe
         eng.set_time_model(ld, th)
     eng.ei_step(fl)
     assert eng.best() == two[0] and np.array_equal(eng.ei_draws(), two[1])
+
+
+def test_handle_statistics(eng):
+    comp, cand, vals, hypers = synthetic_problem(40, 2000, 3, 4, 951)
+    eng.ei_grid(comp, vals, cand, hypers)
+    assert eng.stat("last_step_fused") == 1 and eng.stat("n_cu") >= 64 and eng.stat("flow_fallbacks") == 0
+    comp, cand, vals, hypers = synthetic_problem(300, 2000, 3, 4, 952)
+    eng.ei_grid(comp, vals, cand, hypers)
+    assert eng.stat("last_step_fused") == 0
+    with pytest.raises(ValueError):
+        eng.stat("no_such_counter")
