@@ -312,8 +312,14 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // lean: objective GP only, Cholesky + forward solve, no W = L^-1 (log-likelihood path)
     const int nm = (h->have_time && !lean) ? 2 : 1;
     if (!lean) h->nmodels = nm;
-    const int H = h->H, nh = nm * H, D = h->D, Dp = h->Dp, Np = h->Np;
+    const int H = h->H, nh = nm * H, D = h->D, Dp = h->Dp;
     const int64_t N = h->N;
+    // The EI path pads the observations to the predict GEMM's 128-row tiles.  The log-likelihood path (tile-major, up to
+    // 32 draws) only needs whole 64 x 64 blocks: N <= 64 is ONE diagonal block instead of two, N = 129 .. 192 three
+    // instead of four -- the padding block is an identity that costs a full link of the chain of diagonal blocks
+    // (~17 us of a 64 us call at N <= 64).  Same bits: padding rows never touch the others.
+    const int Np = (lean && nh <= 32) ? (int)round_up(N, SPX_NB) : h->Np;
+    if (lean) h->lean_np = Np;
     const int nblk = Np / SPX_NB;
     const int hs = 3 + D;
 
@@ -1005,12 +1011,12 @@ static int gp_logprob_once(spx_handle* h, double* out)
         if ((rc = h->pin_res.reserve((size_t)h->H * 12))) return rc;
         double* lp_host = (double*)h->pin_res.p;
         int* info_host = (int*)(lp_host + h->H);
-        launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, lp_host, info_host, (int)h->N, h->Np, h->H);
+        launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, lp_host, info_host, (int)h->N, h->lean_np, h->H);
         HIPCHK(hipStreamSynchronize(h->stream));
         memcpy(out, lp_host, (size_t)h->H * 8);
         memcpy(info.data(), info_host, (size_t)h->H * sizeof(int));
     } else {
-        launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->Np, (const int*)h->info.p, h->lp.d(), h->Np, h->H);
+        launch_logprob(h->stream, h->Lm.d(), h->rhs.d(), (size_t)SPX_NB * h->lean_np, (const int*)h->info.p, h->lp.d(), h->lean_np, h->H);
         HIPCHK(hipMemcpyAsync(out, h->lp.p, (size_t)h->H * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)h->H * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

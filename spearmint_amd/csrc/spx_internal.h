@@ -124,6 +124,7 @@ struct spx_handle {
     DevBuf sobol_dirs, sobol_out;                                   // spx_sobol_grid
     DevBuf rhs;                                                     // spx_gp_logprob: [H][64][Np] right-hand-side rows
     DevBuf diagL;                                                   // spx_gp_logprob (tile-major path): diag(L), [H][Np]
+    int lean_np = 0;                                                // padded size of the last lean factorisation (a multiple of 64, not of 128)
     bool lean_tiled = false;                                        // the last lean factorisation used tile-major storage
     int lean_ps = -1;                                               // option "lean_ps": 0 / 1 / -1 = default (on)
     DevBuf ps_flags;                                                // k_lean_step_ps: progress of every diagonal block, [H][nblk]

@@ -701,7 +701,7 @@ def test_in_launch_handoff_under_concurrent_load(eng):
                     assert np.array_equal(eng.gp_logprob(), ref), (name, N, H, rep)
         # no hand-off timed out on the way (a time-out would have switched the handle to one launch per block column, silently
         # but for stderr): the counter a caller can poll says so
-        assert eng.stat("flow_fallbacks") == 0 and eng.stat("flow_enabled") == 1
+        assert eng.stat("flow_fallbacks") == 0
     finally:
         stop.append(1)
         th.join()
@@ -850,9 +850,29 @@ def test_ei_step_is_factor_plus_run_with_one_synchronisation(eng, N, M, D, H, pe
 def test_handle_statistics(eng):
     comp, cand, vals, hypers = synthetic_problem(40, 2000, 3, 4, 951)
     eng.ei_grid(comp, vals, cand, hypers)
+    assert eng.stat("flow_enabled") == 1
     assert eng.stat("last_step_fused") == 1 and eng.stat("n_cu") >= 64 and eng.stat("flow_fallbacks") == 0
     comp, cand, vals, hypers = synthetic_problem(300, 2000, 3, 4, 952)
     eng.ei_grid(comp, vals, cand, hypers)
     assert eng.stat("last_step_fused") == 0
     with pytest.raises(ValueError):
         eng.stat("no_such_counter")
+
+
+@pytest.mark.parametrize("N", [1, 33, 64, 65, 128, 129, 191, 192, 193, 300])
+def test_loglikelihood_pads_to_64_not_128(eng, N):
+    """The log-likelihood path pads the observations to whole 64 x 64 blocks (the EI path to the predict GEMM's 128): one
+    diagonal block for N <= 64, three for 129..192.  Same values as the oracle, batch-size independent bits, and the EI
+    path right after it (which pads to 128 again) is not disturbed."""
+    comp, cand, vals, hypers = synthetic_problem(N, 300, 4, 5, 980 + N)
+    eng.set_observations(comp, vals)
+    eng.set_hypers(hypers); all5 = eng.gp_logprob()
+    for h in range(5):
+        eng.set_hypers(hypers[h:h + 1])
+        assert eng.gp_logprob()[0] == all5[h]
+    ref = np.array([orc.gp_logprob(comp, vals, h[0], h[2], h[1], h[3:]) for h in hypers])
+    assert np.allclose(all5, ref, rtol=1e-10, atol=1e-9)
+    got = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    assert_ei_close(got[3], orc.ei_over_hypers(comp, cand, vals, hypers))
+    eng.set_hypers(hypers)
+    assert np.array_equal(eng.gp_logprob(), all5)
