@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/refresh_$WL
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --skip-extras --workload $WL"
+B="python $R/bench.py --no-cpu-baseline --skip-extras --no-live-traffic --workload $WL"
 # kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 2 --warmup 1 > $O/stats.log 2>&1
 # HBM counters, separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
