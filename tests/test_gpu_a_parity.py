@@ -859,7 +859,7 @@ def test_handle_statistics(eng):
         eng.stat("no_such_counter")
 
 
-@pytest.mark.parametrize("N", [1, 33, 64, 65, 128, 129, 191, 192, 193, 300])
+@pytest.mark.parametrize("N", [2, 33, 64, 65, 128, 129, 191, 192, 193, 300])
 def test_loglikelihood_pads_to_64_not_128(eng, N):
     """The log-likelihood path pads the observations to whole 64 x 64 blocks (the EI path to the predict GEMM's 128): one
     diagonal block for N <= 64, three for 129..192.  Same values as the oracle, batch-size independent bits, and the EI
@@ -876,3 +876,32 @@ def test_loglikelihood_pads_to_64_not_128(eng, N):
     assert_ei_close(got[3], orc.ei_over_hypers(comp, cand, vals, hypers))
     eng.set_hypers(hypers)
     assert np.array_equal(eng.gp_logprob(), all5)
+
+
+@pytest.mark.parametrize("N,M,D,H,per_sec", [(64, 4000, 5, 6, False), (256, 20000, 8, 10, False), (128, 6000, 4, 5, True),
+                                             (700, 9000, 6, 4, True)])
+def test_step_overlap_does_not_change_bits(eng, N, M, D, H, per_sec):
+    """spx_ei_step starts the candidate side of the pass (scaling, the first K(X*,X)) on the second stream beside the
+    factorisation (option step_overlap, default on): same winner, means, per-draw EI and predicted durations as with
+    everything on one stream, fused and general path, with and without a time model."""
+    prob = synthetic_problem(N, M, D, H, 990 + N, per_sec=per_sec)
+    comp, cand, vals, hypers = prob[:4]
+    fl = 3 if per_sec else 2            # (PER_SEC |) KEEP_MOMENTS
+    out = {}
+    try:
+        for ov in (0, 1):
+            eng.set_option("step_overlap", ov)
+            eng.set_observations(comp, vals); eng.set_candidates(cand); eng.set_hypers(hypers)
+            if per_sec:
+                eng.set_time_model(prob[4], prob[5])
+            for _ in range(3):          # repeated: the two streams have no fixed relative timing
+                eng.ei_step(fl)
+            out[ov] = (eng.best(), eng.ei_mean(), eng.ei_draws(), eng.get_moments(H - 1),
+                       eng.get_time_mean(0) if per_sec else None)
+    finally:
+        eng.set_option("step_overlap", -1)
+    a, b = out[0], out[1]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1])
+    if per_sec:
+        assert np.array_equal(a[4], b[4])
