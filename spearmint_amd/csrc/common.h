@@ -117,4 +117,7 @@ void launch_sum_over_draws(hipStream_t s, const double* ei_draw, double* out, in
 void launch_div_scalar(hipStream_t s, double* v, int64_t n, double denom);
 void launch_argmax(hipStream_t s, const double* v, int64_t M, double* blk_val, int64_t* blk_idx,
                    double* out_val, int64_t* out_idx, double* host_mirror = nullptr, const int* info = nullptr, int n_info = 0);
+void launch_mean_argmax(hipStream_t s, const double* ei_draw, double* ei_mean, int64_t M, int64_t Mp, int H, double* blk_val,
+                        int64_t* blk_idx, double* out_val, int64_t* out_idx, double* host_mirror = nullptr,
+                        const int* info = nullptr, int n_info = 0);
 int argmax_blocks(int64_t M);

@@ -756,6 +756,25 @@ __global__ __launch_bounds__(256) void k_argmax_stage1(const double* __restrict_
     if (threadIdx.x == 0) { bv[blockIdx.x] = best; bi[blockIdx.x] = besti; }
 }
 
+// mean over draws and the first argmax stage in one launch (the EI pass's tail: one launch fewer per step; at small N a
+// launch is 5 us of a 140 us step).  ei_mean[c] is written exactly as k_mean_over_draws writes it.
+__global__ __launch_bounds__(256) void k_mean_argmax_stage1(const double* __restrict__ ei_draw, double* __restrict__ ei_mean,
+                                                            int64_t M, int64_t Mp, int H, double* __restrict__ bv,
+                                                            int64_t* __restrict__ bi)
+{
+#pragma clang fp contract(off)
+    double best = 0.0;
+    int64_t besti = -1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const double s = 0.0 + np_pairwise(ei_draw + i, Mp, H);
+        const double x = s / (double)H;
+        ei_mean[i] = x;
+        if (better(x, i, best, besti)) { best = x; besti = i; }
+    }
+    block_argmax(best, besti);
+    if (threadIdx.x == 0) { bv[blockIdx.x] = best; bi[blockIdx.x] = besti; }
+}
+
 // host_mirror (optional, pinned host memory the device can write): {double value, int64 index, int info[n_info]} -- the
 // winner and the factorisation's not-PD flags reach the host with the kernel's own stores, no copy commands behind it
 __global__ __launch_bounds__(256) void k_argmax_stage2(const double* __restrict__ bv,
@@ -784,5 +803,13 @@ void launch_argmax(hipStream_t s, const double* v, int64_t M, double* blk_val, i
 {
     const int nb = argmax_blocks(M);
     hipLaunchKernelGGL(k_argmax_stage1, dim3(nb), dim3(256), 0, s, v, M, blk_val, blk_idx);
+    hipLaunchKernelGGL(k_argmax_stage2, dim3(1), dim3(256), 0, s, blk_val, blk_idx, nb, out_val, out_idx, host_mirror, info, n_info);
+}
+
+void launch_mean_argmax(hipStream_t s, const double* ei_draw, double* ei_mean, int64_t M, int64_t Mp, int H, double* blk_val,
+                        int64_t* blk_idx, double* out_val, int64_t* out_idx, double* host_mirror, const int* info, int n_info)
+{
+    const int nb = argmax_blocks(M);
+    hipLaunchKernelGGL(k_mean_argmax_stage1, dim3(nb), dim3(256), 0, s, ei_draw, ei_mean, M, Mp, H, blk_val, blk_idx);
     hipLaunchKernelGGL(k_argmax_stage2, dim3(1), dim3(256), 0, s, blk_val, blk_idx, nb, out_val, out_idx, host_mirror, info, n_info);
 }

@@ -808,9 +808,8 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     if ((rc = h->pin_res.reserve(16 + (size_t)n_info * sizeof(int)))) return rc;
     double* mirror = (double*)h->pin_res.p;
     TIMED(ST_MEAN_ARGMAX, {
-        launch_mean_over_draws(s, h->ei_draw.d(), h->ei_mean.d(), M, Mp, H);
-        launch_argmax(s, h->ei_mean.d(), M, h->am_val.d(), (int64_t*)h->am_idx.p, h->am_out_val.d(),
-                      (int64_t*)h->am_out_idx.p, mirror, (const int*)h->info.p, n_info);
+        launch_mean_argmax(s, h->ei_draw.d(), h->ei_mean.d(), M, Mp, H, h->am_val.d(), (int64_t*)h->am_idx.p, h->am_out_val.d(),
+                           (int64_t*)h->am_out_idx.p, mirror, (const int*)h->info.p, n_info);
     });
     HIPCHK(hipEventRecord(t1, s));
     HIPCHK(hipStreamSynchronize(s));
