@@ -2,12 +2,12 @@
 
     python scripts/dev/leak_probe.py [reps] [opt=val ...]      e.g.  leak_probe.py 6 lean_flow=0 ei_flow=0
 
-Per op: MiB of device memory NOT returned per create/op/destroy lifetime (hipMemGetInfo through torch), measured after
+Per op: MiB of device memory NOT returned per create/op/destroy lifetime (hipMemGetInfo), measured after
 two settling lifetimes of the same op.  The last line repeats the cycle of tests/test_gpu_z_robustness.py
 ::test_handles_release_their_device_memory."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np, torch
+import numpy as np
 from spearmint_amd.engine import Engine
 from spearmint_amd import sobol
 from spearmint_amd.synthetic import synthetic_problem
@@ -43,8 +43,14 @@ ops = {
 }
 
 
+import ctypes
+_hip = ctypes.CDLL("libamdhip64.so")
+
+
 def free():
-    torch.cuda.synchronize(); return torch.cuda.mem_get_info(0)[0]
+    f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert _hip.hipDeviceSynchronize() == 0 and _hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+    return int(f.value)
 
 
 def full_cycle():
