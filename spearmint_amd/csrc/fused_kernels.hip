@@ -40,7 +40,9 @@
 // of this lane's candidate (the same value in the four lanes (g, li) of a candidate).  NTL is a template parameter so that
 // the whole pass is straight-line code: with run-time tile guards every MFMA sat in a basic block of its own, behind its
 // LDS read and a wait, and the four lock-step epilogue chains were split into four dependent ones.
-template <int QC, int KIND, int NTL>
+// ONECH: the padded input dimension fits one chunk of QC features per k-slot (D <= 16): no chunk loop, so the pass is ONE
+// basic block and the scheduler can start a tile's operand loads under the previous tile's MFMAs.
+template <int QC, int KIND, int NTL, bool ONECH>
 __device__ __forceinline__ void fused_pass(const double* __restrict__ Ws, const double* __restrict__ gl,
                                            const double* __restrict__ Xh, const double* __restrict__ s1h,
                                            const double* __restrict__ pc /* this lane's candidate row + g Q */, double s2v,
@@ -50,7 +52,7 @@ __device__ __forceinline__ void fused_pass(const double* __restrict__ Ws, const 
 #pragma clang fp contract(off)
     const int Q = Dp >> 2;
     double bf[QC];
-    if (nchunks == 1) {
+    if (ONECH || nchunks == 1) {
 #pragma unroll
         for (int q = 0; q < QC; ++q) bf[q] = pc[q];
     }
@@ -62,17 +64,27 @@ __device__ __forceinline__ void fused_pass(const double* __restrict__ Ws, const 
         const int j0 = 16 * kt;
         // ---- Gram tile (k_cov's order: chunks of QC features per k-slot, q ascending) ----
         d4 gr = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int ch = 0; ch < nchunks; ++ch) {
+        if (ONECH) {
             double af[QC];
-            const double* pa = Xh + (size_t)(j0 + li) * Dp + g * Q + ch * QC;
+            const double* pa = Xh + (size_t)(j0 + li) * Dp + g * Q;
 #pragma unroll
             for (int q = 0; q < QC; ++q) af[q] = pa[q];
-            if (nchunks > 1) {
-#pragma unroll
-                for (int q = 0; q < QC; ++q) bf[q] = pc[ch * QC + q];
-            }
+
 #pragma unroll
             for (int q = 0; q < QC; ++q) gr = MFMA_F64(af[q], bf[q], gr);
+        } else {
+            for (int ch = 0; ch < nchunks; ++ch) {
+                double af[QC];
+                const double* pa = Xh + (size_t)(j0 + li) * Dp + g * Q + ch * QC;
+#pragma unroll
+                for (int q = 0; q < QC; ++q) af[q] = pa[q];
+                if (nchunks > 1) {
+#pragma unroll
+                    for (int q = 0; q < QC; ++q) bf[q] = pc[ch * QC + q];
+                }
+#pragma unroll
+                for (int q = 0; q < QC; ++q) gr = MFMA_F64(af[q], bf[q], gr);
+            }
         }
         // ---- correlation function on the accumulator registers: rows j0 + g + 4 r, the four of them in lock step ----
         double t4[4], c4[4], kv[4];      // kv[r] = K*[j0 + g + 4 r][cb + li]
@@ -118,7 +130,7 @@ __device__ __forceinline__ void fused_pass(const double* __restrict__ Ws, const 
     bg_out += bgw[0] + bgw[1];
 }
 
-template <int QC, int KIND>
+template <int QC, int KIND, bool ONECH>
 __global__ __launch_bounds__(FU_THREADS, 1) void k_ei_fused128(
     const double* __restrict__ WT /*[nh][128][128]*/, const double* __restrict__ gamma /*[nh][128]*/,
     const double* __restrict__ Xs /*[nh][128][Dp]*/, const double* __restrict__ s1 /*[nh][128]*/,
@@ -131,6 +143,7 @@ __global__ __launch_bounds__(FU_THREADS, 1) void k_ei_fused128(
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ws = smem;                          // [16 ntl][FU_LDW]
     double* gl = smem + FU_NP * FU_LDW;         // [128] gamma of the draw
+    double* s1l = gl + FU_NP;                   // [128] row norms of the draw's scaled observations
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -144,13 +157,16 @@ __global__ __launch_bounds__(FU_THREADS, 1) void k_ei_fused128(
             const int row = e >> 6, c2 = e & 63;
             *reinterpret_cast<d2*>(Ws + row * FU_LDW + 2 * c2) = *reinterpret_cast<const d2*>(Wg + (size_t)row * FU_NP + 2 * c2);
         }
-        if (tid < FU_NP) gl[tid] = gamma[(size_t)h * FU_NP + tid];
+        if (tid < FU_NP) {
+            gl[tid] = gamma[(size_t)h * FU_NP + tid];
+            s1l[tid] = s1[(size_t)h * FU_NP + tid];
+        }
     }
     __syncthreads();
 
     const double* Xh = Xs + (size_t)h * FU_NP * Dp;
     const double* Ch = Cs + (size_t)h * Mc * Dp;
-    const double* s1h = s1 + (size_t)h * FU_NP;
+    const double* s1h = s1l;
     const double amp2 = htab[h * SPX_HT + 2];
 
     // This workgroup's share of the draw's 16-candidate tiles: [tile0, tile1); wave w takes tile0 + w, + FU_WAVES, ... --
@@ -170,9 +186,9 @@ __global__ __launch_bounds__(FU_THREADS, 1) void k_ei_fused128(
         const double* pc = Ch + (size_t)(cb + li) * Dp + g * Q;
         double ss, bg;
         switch (ntl) {
-#define SPX_FU_CASE(NTL_) case NTL_: fused_pass<QC, KIND, NTL_>(Ws, gl, Xh, s1h, pc, s2v, amp2, N, Dp, nchunks, g, li, ss, bg); break;
+#define SPX_FU_CASE(NTL_) case NTL_: fused_pass<QC, KIND, NTL_, ONECH>(Ws, gl, Xh, s1h, pc, s2v, amp2, N, Dp, nchunks, g, li, ss, bg); break;
             SPX_FU_CASE(1) SPX_FU_CASE(2) SPX_FU_CASE(3) SPX_FU_CASE(4) SPX_FU_CASE(5) SPX_FU_CASE(6) SPX_FU_CASE(7)
-            default: fused_pass<QC, KIND, 8>(Ws, gl, Xh, s1h, pc, s2v, amp2, N, Dp, nchunks, g, li, ss, bg); break;
+            default: fused_pass<QC, KIND, 8, ONECH>(Ws, gl, Xh, s1h, pc, s2v, amp2, N, Dp, nchunks, g, li, ss, bg); break;
 #undef SPX_FU_CASE
         }
         const bool mine = (ps & 3) == g;
@@ -207,7 +223,7 @@ static void launch_fused_kind(hipStream_t s, const double* WT, const double* gam
                               int64_t M, int64_t Mp, int n_cu)
 {
     const int Q = Dp / 4;
-    const size_t lds = (size_t)(FU_NP * FU_LDW + FU_NP) * sizeof(double);   // 145 KB: one workgroup per CU
+    const size_t lds = (size_t)(FU_NP * FU_LDW + 2 * FU_NP) * sizeof(double);   // 146 KB: one workgroup per CU
     const int tiles = Mc / 16;
     // Workgroups per draw.  Every workgroup loads W once (a few us) and its waves take up to FU_PASSES tiles each: the
     // count that minimises (rounds of the chip) x (tiles per wave + the W load, 0.4 of a tile's time); ties: fewer.
@@ -222,16 +238,18 @@ static void launch_fused_kind(hipStream_t s, const double* WT, const double* gam
     }
     if (per < 1) per = 1;
     dim3 grid(per, nh);
-#define SPX_FU_LAUNCH(QC_)                                                                                                \
+#define SPX_FU_LAUNCH(QC_, ONE_)                                                                                          \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ei_fused128<QC_, KIND>),                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ei_fused128<QC_, KIND, ONE_>),                          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
-        hipLaunchKernelGGL((k_ei_fused128<QC_, KIND>), grid, dim3(FU_THREADS), lds, s, WT, gamma, Xs, s1, Cs, s2, htab, time_m, \
-                           best, ei_draw, mom_m, mom_v, N, Mc, Dp, Q / QC_, per, c0, M, Mp);                                   \
+        hipLaunchKernelGGL((k_ei_fused128<QC_, KIND, ONE_>), grid, dim3(FU_THREADS), lds, s, WT, gamma, Xs, s1, Cs, s2, htab,   \
+                           time_m, best, ei_draw, mom_m, mom_v, N, Mc, Dp, Q / QC_, per, c0, M, Mp);                      \
     } while (0)
-    if (Q == 1) SPX_FU_LAUNCH(1);
-    else if (Q == 2) SPX_FU_LAUNCH(2);
-    else SPX_FU_LAUNCH(4);
+    if (Q == 1) SPX_FU_LAUNCH(1, true);
+    else if (Q == 2) SPX_FU_LAUNCH(2, true);
+    else if (Q == 4) SPX_FU_LAUNCH(4, true);
+    // (Q = 8 as one chunk of 8 was tried: -8 % at D = 32, but two of its three instantiations spill 1-3 registers)
+    else SPX_FU_LAUNCH(4, false);
 #undef SPX_FU_LAUNCH
 }
 
