@@ -145,26 +145,36 @@ class GPEIperSecChooser(GPEIBase):
     def _refine(self, points, comp, vals, durs):
         """L-BFGS-B on the summed EI per second (:223-230; the reference ignores pending jobs
         here).  On the GPU the objective uses the dual factorisation the first pass left
-        resident (spx_ei_grad); the bug-compatible mode pairs the draws as the reference does,
-        which the resident pairing does not reproduce, so it stays on the host."""
+        resident (spx_ei_grad_batch), or sets it up when that is not the one summed over."""
         bounds = [(0, 1)] * comp.shape[1]
         if self.covar == "SE":   # getattr(gp, 'grad_SE') at :383
             raise AttributeError("gp has no attribute 'grad_SE': the reference's refinement cannot run with covar=SE")
-        if self._use_gpu_refine(comp.shape[0]) and not self.ref_compat and self._resident_plain:
-            return refine.lbfgs_many(self.engine().ei_grad_batch, points, bounds, log=log)
-        else:
-            rows, trows = (self.hyper_samples[:self.mcmc_iters],
-                           (self.time_hyper_samples[:self.mcmc_iters] if self.ref_compat
-                            else self.time_hyper_samples[-self.mcmc_iters:]))
-            models = [hostgp.PerSecPointModel(comp, vals, durs, h, t, self.covar) for h, t in zip(rows, trows)]
+        rows, trows = (self.hyper_samples[:self.mcmc_iters],
+                       (self.time_hyper_samples[:self.mcmc_iters] if self.ref_compat
+                        else self.time_hyper_samples[-self.mcmc_iters:]))
+        if self._use_gpu_refine(comp.shape[0]):
+            eng = self.engine()
+            if self.ref_compat or not self._resident_plain:
+                # the engine does not hold the dual factorisation this objective sums over -- bug-compatible mode pairs
+                # the draws differently from the EI pass (:322-434 iterate the never-cleared list from its start), and with
+                # pending jobs the EI pass left [comp; pend] resident -- so it is set up here: one factorisation, then
+                # every refinement point of every L-BFGS-B instance goes through spx_ei_grad_batch as usual
+                eng.set_observations(comp, vals)
+                eng.set_hypers(self._rows(rows))
+                eng.set_time_model(durs, self._rows(trows))
+                eng.factor()
+                self._lp_key = None
+                self._resident_plain = False
+            return refine.lbfgs_many(eng.ei_grad_batch, points, bounds, log=log)
+        models = [hostgp.PerSecPointModel(comp, vals, durs, h, t, self.covar) for h, t in zip(rows, trows)]
 
-            def objective(x):
-                total, grad = 0.0, np.zeros(x.shape[0])
-                for m in models:
-                    e, g = m.neg_ei_and_grad(x)
-                    total += e
-                    grad = grad + g
-                return total, grad
+        def objective(x):
+            total, grad = 0.0, np.zeros(x.shape[0])
+            for m in models:
+                e, g = m.neg_ei_and_grad(x)
+                total += e
+                grad = grad + g
+            return total, grad
 
         out = np.array(points, dtype=float, copy=True)
         for i in range(out.shape[0]):

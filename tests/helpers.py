@@ -25,9 +25,11 @@ class OracleEngine(object):
 
     def set_hypers(self, hypers):
         self.hypers, self.fant = np.atleast_2d(hypers), None
+        self._time_set = False          # spx_set_hypers drops the time model, as the library does
 
     def set_time_model(self, log_durs, time_hypers):
         self.log_durs, self.time_hypers = np.asarray(log_durs, float), np.atleast_2d(time_hypers)
+        self._time_set = True
 
     def get_time_mean(self, draw):
         import scipy.linalg as spla
@@ -38,6 +40,9 @@ class OracleEngine(object):
 
     def factor(self):
         self.chols = [orc.posterior(self.comp, self.vals, h)[1] for h in self.hypers]
+        # what spx_ei_grad_batch works against from here on: this factorisation (and its time model, if one is set)
+        self._last_comp, self._last_vals, self._last_rows = self.comp, self.vals, self.hypers
+        self._last_time = (self.log_durs, self.time_hypers) if getattr(self, "_time_set", False) else None
 
     def gp_logprob(self):
         """The sampler's data term for every resident hyper row [mean, noise, amp2, ls...] (-inf where the covariance
