@@ -589,50 +589,42 @@ void launch_ei_finalize(hipStream_t s, const double* part_ss, const double* part
 }
 
 
-// EI against S fantasies, averaged over S in numpy's pairwise order
-// (np.mean(ei, axis=1) on the (M, S) array of GPEIChooser.py:261-266).
-__global__ __launch_bounds__(256) void k_ei_finalize_fant(
+// EI against S fantasies, averaged over S in numpy's pairwise order (np.mean(ei, axis=1) on the (M, S) array of
+// GPEIChooser.py:261-266), in two launches since round 4: every (candidate, draw, fantasy) EI value by a thread of its own
+// (k_ei_fant_values; the single-launch form walked the S fantasies of a candidate in ONE thread -- 39 workgroups per launch
+// at S = 100, 338 ms of an 807 ms pass at C3 size), then the ordered sum over S per candidate (k_ei_fant_mean: np_sum.h, the
+// same additions in the same order as the streaming form it replaces: eight accumulators, the tree, the tail).
+__global__ __launch_bounds__(256) void k_ei_fant_values(
     const double* __restrict__ part_ss, const double* __restrict__ part_bgS,
-    const double* __restrict__ htab, const double* __restrict__ bests /*[nh][S]*/,
-    const double* __restrict__ time_m, double* __restrict__ ei_draw, int nrb, int Mc, int nh,
-    int S, int64_t c0, int64_t M, int64_t Mp, int h0, double* __restrict__ ei_s /*[nh][S][Mc] when S > 128*/)
+    const double* __restrict__ htab, const double* __restrict__ bests /*[nh][S]*/, int nrb, int Mc, int nh,
+    int S, int64_t c0, int64_t M, double* __restrict__ ei_s /*[nh][S][Mc]*/)
 {
 #pragma clang fp contract(off)
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int h = blockIdx.y;
+    const int h = blockIdx.y / S, sidx = blockIdx.y - h * S;
     if (c >= Mc || c0 + c >= M) return;
     double ss = 0.0;
     for (int ib = 0; ib < nrb; ++ib) ss += part_ss[((size_t)ib * nh + h) * Mc + c];
     const double mean = htab[h * SPX_HT + 0];
     const double func_v = htab[h * SPX_HT + 3] - ss;
-    const double* bh = bests + (size_t)h * S;
-    double r8[8];
-    double res = -0.0;
-    const int nfull = (S < 8) ? 0 : S - (S % 8);
-    for (int sidx = 0; sidx < S; ++sidx) {
-        double bg = 0.0;
-        for (int ib = 0; ib < nrb; ++ib) {
-            const size_t o0 = ((((size_t)ib * 2 + 0) * nh + h) * S + sidx) * Mc + c;
-            const size_t o1 = ((((size_t)ib * 2 + 1) * nh + h) * S + sidx) * Mc + c;
-            bg += part_bgS[o0] + part_bgS[o1];
-        }
-        const double ei = ei_dev(bg + mean, func_v, bh[sidx]);
-        // numpy pairwise_sum: streamed for n <= 128, through memory (recursive halving) beyond
-        if (S > 128) {
-            ei_s[((size_t)h * S + sidx) * Mc + c] = ei;
-        } else if (S < 8) {
-            res += ei;
-        } else if (sidx < 8) {
-            r8[sidx] = ei;
-        } else if (sidx < nfull) {
-            r8[sidx & 7] += ei;
-        } else {
-            if (sidx == nfull) res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-            res += ei;
-        }
+    double bg = 0.0;
+    for (int ib = 0; ib < nrb; ++ib) {
+        const size_t o0 = ((((size_t)ib * 2 + 0) * nh + h) * S + sidx) * Mc + c;
+        const size_t o1 = ((((size_t)ib * 2 + 1) * nh + h) * S + sidx) * Mc + c;
+        bg += part_bgS[o0] + part_bgS[o1];
     }
-    if (S > 128) res = np_pairwise(ei_s + (size_t)h * S * Mc + c, Mc, S);
-    else if (S >= 8 && nfull == S) res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+    ei_s[((size_t)h * S + sidx) * Mc + c] = ei_dev(bg + mean, func_v, bests[(size_t)h * S + sidx]);
+}
+
+__global__ __launch_bounds__(256) void k_ei_fant_mean(const double* __restrict__ ei_s, const double* __restrict__ time_m,
+                                                      double* __restrict__ ei_draw, int Mc, int S, int64_t c0, int64_t M,
+                                                      int64_t Mp, int h0)
+{
+#pragma clang fp contract(off)
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    if (c >= Mc || c0 + c >= M) return;
+    const double res = np_pairwise(ei_s + (size_t)h * S * Mc + c, Mc, S);
     double out = (0.0 + res) / (double)S;
     if (time_m) out = out / time_m[(size_t)h * Mc + c];
     ei_draw[(size_t)(h0 + h) * Mp + c0 + c] = out;
@@ -643,8 +635,9 @@ void launch_ei_finalize_fant(hipStream_t s, const double* part_ss, const double*
                              double* ei_draw, int nrb, int Mc, int nh, int S, int64_t c0, int64_t M,
                              int64_t Mp, int h0, double* ei_s)
 {
-    hipLaunchKernelGGL(k_ei_finalize_fant, dim3((Mc + 255) / 256, nh), dim3(256), 0, s, part_ss,
-                       part_bgS, htab, bests, time_m, ei_draw, nrb, Mc, nh, S, c0, M, Mp, h0, ei_s);
+    hipLaunchKernelGGL(k_ei_fant_values, dim3((Mc + 255) / 256, nh * S), dim3(256), 0, s, part_ss, part_bgS, htab, bests, nrb,
+                       Mc, nh, S, c0, M, ei_s);
+    hipLaunchKernelGGL(k_ei_fant_mean, dim3((Mc + 255) / 256, nh), dim3(256), 0, s, ei_s, time_m, ei_draw, Mc, S, c0, M, Mp, h0);
 }
 
 // ---------------------------------------------------------------------------

@@ -660,14 +660,21 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     plan_chunks(h, &Mc, &Hb);
     const int S = h->S;
     if (S > 0) {
-        // the per-fantasy partial means are [nrb][2][S][Mc]: keep them under 256 MB
-        Hb = 1;
-        int64_t cap = (256ll << 20) / ((int64_t)nrb * 2 * S * 8) / SPX_BN * SPX_BN;
+        // the per-fantasy partial means are [nrb][2][S][Mc]: keep them under 2 GB (of 288: at C3 size with 100 fantasies the
+        // plan's own 28 672-candidate chunks fit; the 256 MB of earlier rounds cut them to 9 856 -- 420 launch pairs of a
+        // few dozen workgroups instead of 140)
+        int64_t cap = (2048ll << 20) / ((int64_t)nrb * 2 * S * 8) / SPX_BN * SPX_BN;
         if (cap < SPX_BN) cap = SPX_BN;
         if (Mc > cap) {
             const int64_t nchunks = (Mp + cap - 1) / cap;
             Mc = round_up((Mp + nchunks - 1) / nchunks, SPX_BN);
         }
+        // ... and as many draws per launch as that leaves room for (small problems: all of them -- ten launch pairs of a
+        // 20 000-candidate pass become one)
+        int64_t hb = (2048ll << 20) / ((int64_t)nrb * 2 * S * 8 * Mc);
+        if (hb > 65535 / S) hb = 65535 / S;       // (grid.y of the per-fantasy EI kernel)
+        if (hb < 1) hb = 1;
+        if (hb < Hb) Hb = (int)hb;
     }
 
     // N <= 128 without fantasies: the whole EI pass of a chunk -- K(X,X*), beta = W K*, the moments, EI -- is one kernel
@@ -683,14 +690,14 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
         if (per_sec && (rc = h->time_m[b].reserve((size_t)H * Mc * 8))) return rc;
         if (b < ns && !fused) {
             if ((rc = h->Kst[b].reserve((size_t)Hb * Np * Mc * 8))) return rc;
-            if (S > 0 && (rc = h->part_bgS[b].reserve((size_t)nrb * 2 * S * Mc * 8))) return rc;
+            if (S > 0 && (rc = h->part_bgS[b].reserve((size_t)nrb * 2 * Hb * S * Mc * 8))) return rc;
         }
     }
     // column sums of beta^2 and beta*gamma per row block for ALL draws of a chunk: written by the
     // GEMM launches and read by one EI-finalize launch per chunk, all on the consumer stream
     if (!fused && (rc = h->part_ss[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
     if (!fused && (rc = h->part_bg[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
-    if (S > 128 && (rc = h->scratch.reserve((size_t)S * Mc * 8))) return rc;
+    if (S > 0 && (rc = h->scratch.reserve((size_t)Hb * S * Mc * 8))) return rc;   // EI per (draw of the group, fantasy, candidate)
     if ((rc = h->ei_draw.reserve((size_t)H * Mp * 8))) return rc;
     if ((rc = h->ei_mean.reserve((size_t)Mp * 8))) return rc;
     if (keep_mom) {
@@ -778,7 +785,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
                 HIPCHK(hipEventRecord(h->ev_p0, Pi));
                 HIPCHK(hipStreamWaitEvent(G, h->ev_p0, 0));
             }
-            // with fantasies (Hb = 1) the launch's partial sums are consumed right away and sit at draw 0
+            // with fantasies the launch's partial sums are consumed right away and sit at draws 0 .. nhb-1
             TIMED_S(ST_PREDICT_GEMM, G, launch_predict_gemm(G, h->gemm_variant, h->WT.d() + (size_t)h0 * nn, h->Kst[k].d(),
                                                             h->gamma.d() + (size_t)h0 * Np, h->part_ss[0].d(),
                                                             h->part_bg[0].d(), Np, mc, nhb, S > 0 ? nhb : H, S > 0 ? 0 : h0,
@@ -790,7 +797,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
                                                                    h->bests.d() + (size_t)h0 * S,
                                                                    per_sec ? tm + (size_t)h0 * mc : nullptr,
                                                                    h->ei_draw.d(), nrb, mc, nhb, S, c0, M, Mp, h0,
-                                                                   S > 128 ? h->scratch.d() : nullptr));
+                                                                   h->scratch.d()));
             if (ns == 2) HIPCHK(hipEventRecord(h->ev_sync[2 + k], G));
         }
         if (S == 0 && !fused)   // every draw of the chunk in one launch
