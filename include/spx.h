@@ -187,6 +187,11 @@ int spx_ei_per_sec_grid(spx_handle* h,
  * factor L (N x N, strict upper = 0) and alpha = K^-1 (vals - mean) (N) of
  * draw `draw` (time model: draw + H).  Any pointer may be NULL.               */
 int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* alpha);
+/* Rows [row0, row0 + nrows) of L (nrows x N, row-major, zeros above the diagonal) and gamma = L^-1 (vals - mean) (N) of one
+ * draw; either pointer may be NULL.  The pending branch (GPEIChooser.py:219-249) needs only the bottom P rows of the factor
+ * of cov([comp; pend]) and gamma: pend_m = L21 gamma[:N] + mean, pend_K = L_S L_S^T - noise I (L21 = rows N.., columns < N;
+ * L_S the trailing P x P block) -- a P x (N + P) block per draw instead of the whole factor.                          */
+int spx_get_factor_rows(spx_handle* h, int32_t draw, int64_t row0, int64_t nrows, double* L_rows, double* gamma);
 /* K(X*,X) of draw `draw` for candidates [c0, c0+nc): N x nc row-major.         */
 int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, double* out);
 /* func_m, func_v (M each) of draw `draw`; needs SPX_FLAG_KEEP_MOMENTS.          */

@@ -363,9 +363,10 @@ class GPEIBase(object):
         fant = np.empty((H, n_comp + n_pend, S))
         bests = np.empty((H, S))
         for h in range(H):
-            chol = eng.get_factor(h, want_K=False, want_alpha=False)[1]
-            fant[h], bests[h] = hostgp.fantasize_pending(comp, pend, vals, hyper_rows[h],
-                                                         chol[:n_comp, :n_comp], randn[h], self.covar)
+            # the bottom P rows of the factor and gamma are all the posterior of the pending points needs (hostgp:
+            # fantasize_from_factor_rows) -- not the N x N sub-Cholesky and two O(N^2 P) host solves against it
+            l_rows, gam = eng.get_factor_rows(h, n_comp, n_pend)
+            fant[h], bests[h] = hostgp.fantasize_from_factor_rows(vals, hyper_rows[h], l_rows, gam, randn[h])
         eng.set_fantasies(fant, bests)
         eng.ei_run()
         idx, _ = eng.best()

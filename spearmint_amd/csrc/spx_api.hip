@@ -953,6 +953,58 @@ int spx_get_factor(spx_handle* h, int32_t draw, double* K, double* L, double* al
     return SPX_OK;
 }
 
+// Rows [row0, row0 + nrows) of L (each N long, zeros above the diagonal) and gamma = L^-1 (vals - mean) of one draw.  What
+// the pending branch needs of the factorisation of cov([comp; pend]) (GPEIChooser.py:219-249): with the P pending points
+// last, the bottom P rows are [ (L_A^-1 B)^T | L_S ] -- B = cov(comp, pend), L_S the factor of the Schur complement -- so the
+// posterior of the pending points is pend_m = L21 gamma[:N] + mean, pend_K = L_S L_S^T - noise I: a P x (N + P) block and one
+// vector per draw instead of the whole N x N factor (1.6 MB instead of 671 MB at N = 2048, 20 draws, P = 4).
+int spx_get_factor_rows(spx_handle* h, int32_t draw, int64_t row0, int64_t nrows, double* L_rows, double* gamma)
+{
+    if (h && h->multi) return spx_multi_get_factor_rows(h->multi, draw, row0, nrows, L_rows, gamma);
+    if (!h || !h->factored) return fail(SPX_ERR_ARG, "spx_get_factor_rows: call spx_factor first");
+    const int nh = h->nmodels * h->H;
+    const int64_t N = h->N;
+    if (draw < 0 || draw >= nh) return fail(SPX_ERR_ARG, "spx_get_factor_rows: draw out of range");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > N) return fail(SPX_ERR_ARG, "spx_get_factor_rows: rows out of range");
+    int rc = ensure_init(h);
+    if (rc) return rc;
+    const int Np = h->Np;
+    const size_t nn = (size_t)Np * Np;
+    if (L_rows && nrows > 0 && h->factor_tiled) {
+        // (tile-major factor: the tiles (I, 0 .. I) of a block row are contiguous; same element map as spx_get_factor)
+        const int nblk = Np / SPX_NB;
+        std::vector<double> T;
+        for (int I = (int)(row0 >> 6); I <= (int)((row0 + nrows - 1) >> 6); ++I) {
+            T.resize((size_t)(I + 1) * 4096);
+            HIPCHK(hipMemcpy(T.data(), h->Lm.d() + (size_t)draw * nn + (size_t)I * nblk * 4096, T.size() * 8, hipMemcpyDeviceToHost));
+            for (int64_t i = std::max<int64_t>(row0, (int64_t)I * 64); i < std::min<int64_t>(row0 + nrows, (int64_t)(I + 1) * 64); ++i) {
+                double* out = L_rows + (size_t)(i - row0) * N;
+                const int ri = (int)(i & 63);
+                for (int64_t j = 0; j < N; ++j) {
+                    double v = 0.0;
+                    if (j <= i) {
+                        const int J = (int)(j >> 6), cj = (int)(j & 63);
+                        const double* tile = T.data() + (size_t)J * 4096;
+                        if (I == J) v = tile[ri * 64 + cj];
+                        else {
+                            const int t = (ri >> 4) * 64 + (ri & 3) * 16 + (cj & 15), q = (cj >> 4) * 4 + ((ri & 15) >> 2);
+                            v = tile[((q >> 1) * 256 + t) * 2 + (q & 1)];
+                        }
+                    }
+                    out[j] = v;
+                }
+            }
+        }
+    } else if (L_rows && nrows > 0) {
+        HIPCHK(hipMemcpy2D(L_rows, (size_t)N * 8, h->Lm.d() + (size_t)draw * nn + (size_t)row0 * Np, (size_t)Np * 8, (size_t)N * 8,
+                           (size_t)nrows, hipMemcpyDeviceToHost));
+        for (int64_t i = row0; i < row0 + nrows; ++i)
+            for (int64_t j = i + 1; j < N; ++j) L_rows[(size_t)(i - row0) * N + j] = 0.0;
+    }
+    if (gamma) HIPCHK(hipMemcpy(gamma, h->gamma.d() + (size_t)draw * Np, (size_t)N * 8, hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
 int spx_get_cross_cov(spx_handle* h, int32_t draw, int64_t c0, int64_t nc, double* out)
 {
     if (h && h->multi) return spx_multi_get_cross_cov(h->multi, draw, c0, nc, out);

@@ -176,6 +176,7 @@ int spx_multi_get_ei_draws(spx_multi* m, double* out);
 int spx_multi_get_moments(spx_multi* m, int32_t draw, double* func_m, double* func_v);
 int spx_multi_get_time_mean(spx_multi* m, int32_t draw, double* out);
 int spx_multi_get_factor(spx_multi* m, int32_t draw, double* K, double* L, double* alpha);
+int spx_multi_get_factor_rows(spx_multi* m, int32_t draw, int64_t row0, int64_t nrows, double* L_rows, double* gamma);
 int spx_multi_get_cross_cov(spx_multi* m, int32_t draw, int64_t c0, int64_t nc, double* out);
 int spx_multi_gp_logprob(spx_multi* m, double* out);
 int spx_multi_ei_grad_batch(spx_multi* m, const double* points, int32_t P, double* neg_ei, double* grad);

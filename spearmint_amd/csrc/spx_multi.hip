@@ -872,6 +872,13 @@ static int owner_of_draw(const spx_multi* m, int32_t draw, int* kid, int* ld)
     return fail(SPX_ERR_ARG, "draw out of range");
 }
 
+int spx_multi_get_factor_rows(spx_multi* m, int32_t draw, int64_t row0, int64_t nrows, double* L_rows, double* gamma)
+{
+    int kid = 0, ld = draw;   // replicated (ph = 1): every device holds every draw
+    if (m->ph > 1) { int rc = owner_of_draw(m, draw, &kid, &ld); if (rc) return rc; }
+    return spx_get_factor_rows(m->kids[kid], ld, row0, nrows, L_rows, gamma);
+}
+
 int spx_multi_get_factor(spx_multi* m, int32_t draw, double* K, double* L, double* alpha)
 {
     int kid = 0, ld = draw;   // replicated (ph = 1): every device holds every draw

@@ -65,6 +65,7 @@ ABI = {
                                            _c_double_p, ctypes.c_int32, ctypes.c_int32, _c_double_p,
                                            _c_double_p, _c_int64_p, _c_double_p]),
     "spx_get_factor": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    "spx_get_factor_rows": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     "spx_get_cross_cov": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
     "spx_get_moments": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p, _c_double_p]),
     "spx_get_time_mean": (ctypes.c_int, [_vp, ctypes.c_int32, _c_double_p]),
@@ -354,6 +355,14 @@ class Engine(object):
         a = np.empty(N) if want_alpha else None
         self._check(self._lib.spx_get_factor(self._h, int(draw), _dp(K), _dp(L), _dp(a)))
         return K, L, a
+
+    def get_factor_rows(self, draw, row0, nrows, want_gamma=True):
+        """Rows [row0, row0 + nrows) of L (nrows x N) and gamma = L^-1 (vals - mean) (N) of one draw."""
+        rows = np.empty((int(nrows), self.N))
+        gam = np.empty(self.N) if want_gamma else None
+        self._check(self._lib.spx_get_factor_rows(self._h, int(draw), int(row0), int(nrows), _dp(rows),
+                                                  _dp(gam) if want_gamma else None))
+        return rows, gam
 
     def get_cross_cov(self, draw, c0=0, nc=None):
         nc = self.M - c0 if nc is None else nc

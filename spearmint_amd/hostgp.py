@@ -265,6 +265,26 @@ def fantasize_pending(comp, pend, vals, hyper_row, obsv_chol, randn_ps, covar="M
     return fant_vals, np.min(fant_vals, axis=0)
 
 
+def fantasize_from_factor_rows(vals, hyper_row, l_rows, gamma, randn_ps):
+    """The same posterior from the bottom P rows of the Cholesky factor of cov([comp; pend]) + noise I and
+    gamma = L^-1 ([vals; 0] - mean), which is all the GPU path ships home (spx_get_factor_rows): with
+    L = [[L_A, 0], [L21, L_S]],  L21 = (L_A^-1 B)^T  and  L_S L_S^T = C - B^T A^-1 B  (B = cov(comp, pend),
+    C = pend_kappa + noise I), so   pend_m = B^T A^-1 (vals - mean) + mean = L21 gamma[:N] + mean   and
+    pend_K = pend_kappa - B^T A^-1 B = L_S L_S^T - noise I   -- GPEIChooser.py:229-236 without the two
+    O(N^2 P) solves against the N x N sub-Cholesky and without moving that factor to the host."""
+    mean, noise = hyper_row[0], hyper_row[1]
+    n = vals.shape[0]
+    p = l_rows.shape[0]
+    l21, ls_ = l_rows[:, :n], l_rows[:, n:n + p]
+    pend_m = np.dot(l21, gamma[:n]) + mean
+    pend_k = np.dot(ls_, ls_.T) - noise * np.eye(p)
+    pend_chol = spla.cholesky(pend_k, lower=True)
+    pend_fant = np.dot(pend_chol, randn_ps) + pend_m[:, None]
+    s = randn_ps.shape[1]
+    fant_vals = np.concatenate((np.tile(vals[:, np.newaxis], (1, s)), pend_fant))
+    return fant_vals, np.min(fant_vals, axis=0)
+
+
 class PendingPointModel(object):
     """EI (averaged over fantasies) and its gradient at a few points, with
     pending experiments -- the host-side refinement of GPEIOptChooser.py:441-525."""

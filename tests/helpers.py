@@ -58,6 +58,12 @@ class OracleEngine(object):
     def get_factor(self, draw, want_K=True, want_L=True, want_alpha=True):
         return None, self.chols[draw], None
 
+    def get_factor_rows(self, draw, row0, nrows, want_gamma=True):
+        import scipy.linalg as spla
+        chol = self.chols[draw]
+        gam = spla.solve_triangular(chol, self.vals - self.hypers[draw][0], lower=True) if want_gamma else None
+        return np.array(chol[row0:row0 + nrows, :]), gam
+
     def set_fantasies(self, fant, bests):
         self.fant, self.bests = np.asarray(fant, float), np.asarray(bests, float)
 

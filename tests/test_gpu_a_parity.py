@@ -905,3 +905,26 @@ def test_step_overlap_does_not_change_bits(eng, N, M, D, H, per_sec):
     assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1])
     if per_sec:
         assert np.array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("N,P,D,H,flow", [(130, 3, 4, 3, 1), (300, 5, 6, 2, 1), (70, 2, 3, 2, 0), (1000, 4, 8, 2, 1)])
+def test_factor_rows_are_the_rows_of_the_factor(eng, N, P, D, H, flow):
+    """spx_get_factor_rows (bottom P rows of L and gamma: what the pending branch brings home instead of the whole factor)
+    against spx_get_factor and the oracle, tile-major (ei_flow=1) and row-major factor storage."""
+    import scipy.linalg as spla
+    comp, cand, vals, hypers = synthetic_problem(N + P, 200, D, H, 995 + N)
+    try:
+        eng.set_option("ei_flow", flow)
+        eng.set_observations(comp, vals); eng.set_candidates(cand); eng.set_hypers(hypers); eng.factor()
+        for h in range(H):
+            L = eng.get_factor(h, want_K=False, want_alpha=False)[1]
+            rows, gam = eng.get_factor_rows(h, N, P)
+            assert np.array_equal(rows, L[N:, :])
+            mid, _ = eng.get_factor_rows(h, 60, 9, want_gamma=False)       # a range that straddles a 64-row block
+            assert np.array_equal(mid, L[60:69, :])
+            ref = spla.solve_triangular(orc.posterior(comp, vals, hypers[h])[1], vals - hypers[h][0], lower=True)
+            assert np.allclose(gam, ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+        with pytest.raises(ValueError):
+            eng.get_factor_rows(0, N, P + 1)
+    finally:
+        eng.set_option("ei_flow", -1)

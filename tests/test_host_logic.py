@@ -655,3 +655,24 @@ def test_batched_row_builder_equals_the_per_point_one(tmp_path):
             assert (va.errors[k] is None) == (vb.errors[k] is None)
             assert va.values[k] == vb.values[k] or (np.isnan(va.values[k]) and np.isnan(vb.values[k]))
         assert [np.isneginf(v) for v in va.values] == [np.isneginf(v) for v in vb.values]
+
+
+def test_fantasies_from_the_bottom_rows_of_the_factor_equal_the_reference_form():
+    """hostgp.fantasize_from_factor_rows (what the GPU path uses: the bottom P rows of chol(cov([comp; pend]) + noise I)
+    and gamma) against hostgp.fantasize_pending (GPEIChooser.py:219-249 restated: the N x N sub-Cholesky and two solves
+    against it): the same fantasies and bests to rounding, also with a pending point 1e-4 away from an observation."""
+    import scipy.linalg as spla
+    rs = np.random.RandomState(4)
+    for n, p, d, kname in ((30, 3, 2, "Matern52"), (120, 5, 6, "Matern52"), (65, 1, 3, "ARDSE"), (40, 4, 2, "Matern32")):
+        comp, pend = rs.rand(n, d), rs.rand(p, d)
+        pend[0] = comp[3] + 1e-4
+        vals = np.sin(3 * comp).sum(axis=1) + 0.01 * rs.randn(n)
+        row = np.concatenate(([vals.mean(), 10.0 ** rs.uniform(-4, -2), np.exp(0.5 * rs.randn())], rs.uniform(0.3, 2.0, d)))
+        cp = np.concatenate((comp, pend))
+        chol = spla.cholesky(hostgp.obs_cov(row[2], row[1], row[3:], cp, kname), lower=True)
+        gamma = spla.solve_triangular(chol, np.concatenate((vals, np.zeros(p))) - row[0], lower=True)
+        z = rs.randn(p, 50)
+        f0, b0 = hostgp.fantasize_pending(comp, pend, vals, row, chol[:n, :n], z, kname)
+        f1, b1 = hostgp.fantasize_from_factor_rows(vals, row, chol[n:, :], gamma, z)
+        scale = np.abs(f0).max()
+        assert np.allclose(f1, f0, rtol=0, atol=1e-9 * scale) and np.allclose(b1, b0, rtol=0, atol=1e-9 * scale)
