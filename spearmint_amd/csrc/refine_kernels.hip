@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void k_trimv_multi(const double* __restrict__ 
                                                      const double* __restrict__ rhs,
                                                      double* __restrict__ out, int Np, int P)
 {
-    __shared__ double r[PB][256];
-    __shared__ double part[4][PB][64];
+    // one array for both uses: r[q][t] = sm[q * 256 + t] during the loop, part[w][q][lane] = sm[(w * PB + q) * 64 + lane] after it
+    __shared__ double sm[PB * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = blockIdx.y, p0 = blockIdx.z * PB;
     const int np = min(PB, P - p0);
@@ -109,21 +109,36 @@ __global__ __launch_bounds__(256) void k_trimv_multi(const double* __restrict__ 
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PB; ++q)
-            r[q][threadIdx.x] = (q < np && jb + threadIdx.x < Np) ? rh[(size_t)q * Np + jb + threadIdx.x] : 0.0;
+            sm[q * 256 + threadIdx.x] = (q < np && jb + threadIdx.x < Np) ? rh[(size_t)q * Np + jb + threadIdx.x] : 0.0;
         __syncthreads();
         const int jn = (i < Np) ? min(256, i - jb + 1) : 0;     // this row needs j = jb .. jb + jn - 1
-        for (int t = wave; t < jn; t += 4) {
-            const double w = Wh[(size_t)(jb + t) * Np + i];
+        // eight loads of W in flight per wave (the loop is one dependent chain per row: with the compiler's own
+        // unrolling it was a memory round trip per four rows); the sums still run over j in increasing order
+        const double* wp = Wh + (size_t)jb * Np + i;
+        int t = wave;
+        for (; t + 28 < jn; t += 32) {
+            double w[8];
 #pragma unroll
-            for (int q = 0; q < PB; ++q) acc[q] += w * r[q][t];
+            for (int u = 0; u < 8; ++u) w[u] = wp[(size_t)(t + 4 * u) * Np];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < PB; ++q) acc[q] = fma(w[u], sm[q * 256 + t + 4 * u], acc[q]);
+        }
+        for (; t < jn; t += 4) {
+            const double w = wp[(size_t)t * Np];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) acc[q] = fma(w, sm[q * 256 + t], acc[q]);
         }
     }
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < PB; ++q) part[wave][q][lane] = acc[q];
+    for (int q = 0; q < PB; ++q) sm[(wave * PB + q) * 64 + lane] = acc[q];
     __syncthreads();
     if (wave == 0 && i < Np)
         for (int q = 0; q < np; ++q)
-            out[((size_t)h * P + p0 + q) * Np + i] = ((part[0][q][lane] + part[1][q][lane]) + part[2][q][lane]) + part[3][q][lane];
+            out[((size_t)h * P + p0 + q) * Np + i] =
+                ((sm[(0 * PB + q) * 64 + lane] + sm[(1 * PB + q) * 64 + lane]) + sm[(2 * PB + q) * 64 + lane]) + sm[(3 * PB + q) * 64 + lane];
 }
 
 void launch_trimv_multi(hipStream_t s, const double* WT, const double* rhs, double* out, int Np, int nh, int P)
@@ -146,12 +161,30 @@ __global__ __launch_bounds__(256) void k_trimvT_multi(const double* __restrict__
     double acc[PB];
 #pragma unroll
     for (int q = 0; q < PB; ++q) acc[q] = 0.0;
-    for (int i = (j & ~63) + lane; i < Np; i += 64)
+    // four 64-element segments of the row per trip (their loads in flight together: the row is a chain of memory round trips
+    // otherwise); each lane still adds its elements in increasing i, one fma each: the same sums
+    int i = (j & ~63) + lane;
+    for (; i + 192 < Np; i += 256) {
+        double w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = (i + 64 * u >= j) ? row[i + 64 * u] : 0.0;
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
+            if (q < np) {
+                double rv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rv[u] = rh[(size_t)q * Np + i + 64 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + 64 * u >= j) acc[q] = fma(w[u], rv[u], acc[q]);
+            }
+    }
+    for (; i < Np; i += 64)
         if (i >= j) {
             const double w = row[i];
 #pragma unroll
             for (int q = 0; q < PB; ++q)
-                if (q < np) acc[q] += w * rh[(size_t)q * Np + i];
+                if (q < np) acc[q] = fma(w, rh[(size_t)q * Np + i], acc[q]);
         }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
