@@ -53,6 +53,10 @@ typedef struct spx_handle spx_handle;
                                     for spx_get_moments() (test / debug)          */
 #define SPX_FLAG_TIMING      4   /* bracket every kernel launch with HIP events
                                     on the handle's stream (spx_get_timings)      */
+#define SPX_FLAG_TIME_ONLY   8   /* with PER_SEC | KEEP_MOMENTS: only the log-duration GP's predicted durations are
+                                    computed (spx_get_time_mean); no EI, no winner.  The per-second chooser's pending
+                                    branch needs exactly that from its first pass (GPEIperSecChooser.py:492-548: the two
+                                    GPs have different observation sets there)                                      */
 
 /* ---- lifetime ---------------------------------------------------------- */
 /* Create an engine on HIP device `device_id` (lazy: the first call that needs

@@ -123,7 +123,7 @@ class GPEIperSecChooser(GPEIBase):
         [comp; pend], GPU) divided by the predicted duration (time GP over comp only,
         GPU).  The two GPs have different observation sets, so they are two engine
         passes; the final M x H division, mean and argmax are a tiny host step."""
-        from ..engine import FLAG_KEEP_MOMENTS, FLAG_PER_SEC
+        from ..engine import FLAG_KEEP_MOMENTS, FLAG_PER_SEC, FLAG_TIME_ONLY
         eng = self.engine()
         H = rows.shape[0]
         # pass 1: durations.  The fantasy normals are drawn first, where the reference
@@ -133,7 +133,7 @@ class GPEIperSecChooser(GPEIBase):
         eng.set_candidates(cand)
         eng.set_hypers(rows)
         eng.set_time_model(durs, trows)
-        eng.ei_step(FLAG_PER_SEC | FLAG_KEEP_MOMENTS)      # factor + run, one synchronisation
+        eng.ei_step(FLAG_PER_SEC | FLAG_KEEP_MOMENTS | FLAG_TIME_ONLY)   # factor + the predicted durations, nothing else
         time_m = np.stack([eng.get_time_mean(h) for h in range(H)], axis=1)
         # pass 2: EI averaged over fantasies
         _, _, ei = self._ei_with_pending_gpu(comp, pend, cand, vals, rows, randn, True)

@@ -174,7 +174,7 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "covar")) {   // SPX_COVAR_*: the reference's covar= (gp.py:87-132)
         if (value < SPX_COVAR_MATERN52 || value > SPX_COVAR_SE)
             return fail(SPX_ERR_ARG, "spx_set_option: covar=%lld is not one of SPX_COVAR_*", (long long)value);
-        if (h->cov_kind != (int)value) { h->factored = false; h->ran = false; h->S = 0; }
+        if (h->cov_kind != (int)value) { h->factored = false; h->ran = false; h->ran_time = false; h->S = 0; }
         h->cov_kind = (int)value;
         return SPX_OK;
     }
@@ -248,7 +248,7 @@ int spx_set_observations(spx_handle* h, const double* comp, const double* vals, 
     }
     h->best = b;
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->have_obs = true; h->have_time = false; h->factored = false; h->ran = false; h->S = 0;
+    h->have_obs = true; h->have_time = false; h->factored = false; h->ran = false; h->ran_time = false; h->S = 0;
     return SPX_OK;
 }
 
@@ -266,7 +266,7 @@ int spx_set_candidates(spx_handle* h, const double* cand, int64_t M, int32_t D, 
     if ((rc = h->cand.reserve((size_t)M * D * 8))) return rc;
     HIPCHK(hipMemcpyAsync(h->cand.p, cand, (size_t)M * D * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->have_cand = true; h->ran = false;
+    h->have_cand = true; h->ran = false; h->ran_time = false;
     return SPX_OK;
 }
 
@@ -277,7 +277,7 @@ int spx_set_hypers(spx_handle* h, const double* hypers, int32_t H)
     if (!h->have_obs) return fail(SPX_ERR_ARG, "spx_set_hypers: call spx_set_observations first");
     h->H = H;
     h->hyp_host.assign(hypers, hypers + (size_t)H * (3 + h->D));
-    h->have_hyp = true; h->have_time = false; h->factored = false; h->ran = false; h->S = 0;
+    h->have_hyp = true; h->have_time = false; h->factored = false; h->ran = false; h->ran_time = false; h->S = 0;
     return SPX_OK;
 }
 
@@ -294,7 +294,7 @@ int spx_set_time_model(spx_handle* h, const double* log_durs, const double* time
     HIPCHK(hipMemcpyAsync(h->ldur.p, log_durs, (size_t)h->N * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->thyp_host.assign(time_hypers, time_hypers + (size_t)h->H * (3 + h->D));
-    h->have_time = true; h->factored = false; h->ran = false;
+    h->have_time = true; h->factored = false; h->ran = false; h->ran_time = false;
     return SPX_OK;
 }
 
@@ -505,7 +505,7 @@ static int finish_factor(spx_handle* h, const std::vector<int>& info, bool toler
     for (int i = 0; i < nh; ++i)
         if (info[i]) { h->not_pd_draw = i; h->not_pd_pivot = info[i] - 1; break; }
     h->factored = !lean;
-    h->ran = false;
+    h->ran = false; h->ran_time = false;
     h->S = 0;
     if (h->not_pd_draw >= 0 && !tolerate_not_pd) {
         h->factored = false;
@@ -571,7 +571,7 @@ int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, in
     HIPCHK(hipGetLastError());
     h->S = S;
     h->alphaS_valid = false;
-    h->ran = false;
+    h->ran = false; h->ran_time = false;
     return SPX_OK;
 }
 
@@ -607,7 +607,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending);
 int spx_ei_run(spx_handle* h, int32_t flags)
 {
     if (!h) return fail(SPX_ERR_ARG, "spx_ei_run: null handle");
-    if (h->multi) return spx_multi_ei_run(h->multi, flags);
+    if (h->multi) return spx_multi_ei_run(h->multi, flags & ~SPX_FLAG_TIME_ONLY);   // (several GPUs: the full pass; the durations are a by-product)
     return ei_run_impl(h, flags, false);
 }
 
@@ -620,7 +620,7 @@ int spx_ei_step(spx_handle* h, int32_t flags)
     if (!h) return fail(SPX_ERR_ARG, "spx_ei_step: null handle");
     if (h->multi) {
         int rc = spx_multi_factor(h->multi);
-        return rc ? rc : spx_multi_ei_run(h->multi, flags);
+        return rc ? rc : spx_multi_ei_run(h->multi, flags & ~SPX_FLAG_TIME_ONLY);
     }
     if (h->timing || (flags & SPX_FLAG_TIMING) || !h->have_cand) {   // stage timers bracket each call: keep the two-call form
         int rc = spx_factor(h);
@@ -649,6 +649,10 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     if (!h->have_cand) return fail(SPX_ERR_ARG, "spx_ei_run: no candidates set");
     const bool per_sec = (flags & SPX_FLAG_PER_SEC) != 0;
     const bool keep_mom = (flags & SPX_FLAG_KEEP_MOMENTS) != 0;
+    const bool time_only = (flags & SPX_FLAG_TIME_ONLY) != 0;
+    if (time_only && !(per_sec && keep_mom))
+        return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_TIME_ONLY needs SPX_FLAG_PER_SEC | SPX_FLAG_KEEP_MOMENTS");
+    if (time_only && h->comm) return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_TIME_ONLY has no winner to exchange (communicator attached)");
     if (per_sec && h->nmodels != 2)
         return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_PER_SEC needs spx_set_time_model before spx_factor");
     int rc = ensure_init(h);
@@ -688,15 +692,15 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
         if ((rc = h->Cs[b].reserve((size_t)H * Mc * Dp * 8))) return rc;
         if ((rc = h->s2[b].reserve((size_t)H * Mc * 8))) return rc;
         if (per_sec && (rc = h->time_m[b].reserve((size_t)H * Mc * 8))) return rc;
-        if (b < ns && !fused) {
+        if (b < ns && !fused && !time_only) {
             if ((rc = h->Kst[b].reserve((size_t)Hb * Np * Mc * 8))) return rc;
             if (S > 0 && (rc = h->part_bgS[b].reserve((size_t)nrb * 2 * Hb * S * Mc * 8))) return rc;
         }
     }
     // column sums of beta^2 and beta*gamma per row block for ALL draws of a chunk: written by the
     // GEMM launches and read by one EI-finalize launch per chunk, all on the consumer stream
-    if (!fused && (rc = h->part_ss[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
-    if (!fused && (rc = h->part_bg[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
+    if (!fused && !time_only && (rc = h->part_ss[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
+    if (!fused && !time_only && (rc = h->part_bg[0].reserve((size_t)nrb * H * Mc * 8))) return rc;
     if (S > 0 && (rc = h->scratch.reserve((size_t)Hb * S * Mc * 8))) return rc;   // EI per (draw of the group, fantasy, candidate)
     if ((rc = h->ei_draw.reserve((size_t)H * Mp * 8))) return rc;
     if ((rc = h->ei_mean.reserve((size_t)Mp * 8))) return rc;
@@ -759,6 +763,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
                 HIPCHK(hipMemcpy2DAsync(h->mom_t.d() + c0, (size_t)Mp * 8, tm, (size_t)mc * 8,
                                         (size_t)std::min<int64_t>(mc, Mp - c0) * 8, (size_t)H, hipMemcpyDeviceToDevice, T));
         }
+        if (time_only) continue;      // (the predicted durations of the chunk are in mom_t: nothing else was asked for)
         // 2 * cand / ls and |cand / ls|^2 for every draw (one launch per chunk)
         hipStream_t Pc = (chunk == 0) ? P0 : P;       // (the first chunk's producer work of a step: beside the factorisation)
         TIMED_S(ST_SCALE, Pc, launch_scale_rows(Pc, xc, nreal, mc, D, Dp, ls, hs, H, 2.0, Cs, s2));
@@ -825,7 +830,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     h->best_idx = ((const int64_t*)mirror)[1];
     if (factor_pending) {
         std::vector<int> info((const int*)(mirror + 2), (const int*)(mirror + 2) + n_info);
-        if ((rc = finish_factor(h, info, false, false))) { h->ran = false; return rc; }
+        if ((rc = finish_factor(h, info, false, false))) { h->ran = false; h->ran_time = false; return rc; }
     }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, t0, t1);
@@ -833,9 +838,10 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
         ev_collect(h);
         h->st_ms[ST_EI_RUN_TOTAL] += ms; h->st_n[ST_EI_RUN_TOTAL] += 1;
     }
-    h->ran = true;
+    h->ran = !time_only;             // (a time-only pass has no EI results: spx_get_best & co. refuse)
+    h->ran_time = time_only;
     h->ran_2d = false;
-    h->ran_moments = keep_mom && S == 0;
+    h->ran_moments = keep_mom && S == 0 && !time_only;
     if (h->comm) return spx_comm_exchange(h);   // one process per GPU: the winner over all ranks
     return SPX_OK;
 }
@@ -893,7 +899,7 @@ int spx_get_moments(spx_handle* h, int32_t draw, double* func_m, double* func_v)
 int spx_get_time_mean(spx_handle* h, int32_t draw, double* out)
 {
     if (h && h->multi) return spx_multi_get_time_mean(h->multi, draw, out);
-    if (!h || !out || !h->ran || !h->ran_moments || h->nmodels != 2)
+    if (!h || !out || !((h->ran && h->ran_moments) || h->ran_time) || h->nmodels != 2)
         return fail(SPX_ERR_ARG, "spx_get_time_mean: run spx_ei_run with SPX_FLAG_PER_SEC | SPX_FLAG_KEEP_MOMENTS first");
     if (draw < 0 || draw >= h->H) return fail(SPX_ERR_ARG, "spx_get_time_mean: draw out of range");
     int rc = ensure_init(h);
@@ -1151,7 +1157,7 @@ int spx_sobol_grid(spx_handle* h, const uint32_t* dirs, int32_t dim_max, int32_t
     if (as_candidates) {
         if (!h->have_obs) { h->D = dim; h->Dp = padded_dim(dim); }
         h->M = n; h->index_base = 0;
-        h->have_cand = true; h->ran = false;
+        h->have_cand = true; h->ran = false; h->ran_time = false;
     }
     return SPX_OK;
 }

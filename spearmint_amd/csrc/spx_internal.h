@@ -90,6 +90,7 @@ struct spx_handle {
     int D = 0, Dp = 0, Np = 0, H = 0;
     bool have_obs = false, have_cand = false, have_hyp = false, have_time = false;
     bool factored = false, ran = false, ran_moments = false;
+    bool ran_time = false;           // the last pass was SPX_FLAG_TIME_ONLY: predicted durations are valid, EI results are not
     int nmodels = 1;  // 1 = objective GP only, 2 = + log-duration GP
     double best = 0.0;
     int not_pd_draw = -1, not_pd_pivot = -1;

@@ -27,6 +27,7 @@ COVAR = {"Matern52": 0, "Matern32": 1, "ARDSE": 2, "SE": 3}   # include/spx.h SP
 FLAG_PER_SEC = 1
 FLAG_KEEP_MOMENTS = 2
 FLAG_TIMING = 4
+FLAG_TIME_ONLY = 8
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int64_p = ctypes.POINTER(ctypes.c_int64)

@@ -928,3 +928,23 @@ def test_factor_rows_are_the_rows_of_the_factor(eng, N, P, D, H, flow):
             eng.get_factor_rows(0, N, P + 1)
     finally:
         eng.set_option("ei_flow", -1)
+
+
+def test_time_only_pass_gives_the_predicted_durations(eng):
+    """SPX_FLAG_TIME_ONLY (with PER_SEC | KEEP_MOMENTS): the predicted durations of the full per-second pass, bit for bit,
+    without the EI work; EI getters refuse afterwards; a change of inputs invalidates them."""
+    comp, cand, vals, hypers, ld, th = synthetic_problem(150, 5000, 5, 4, 997, per_sec=True)
+    eng.set_observations(comp, vals); eng.set_candidates(cand); eng.set_hypers(hypers); eng.set_time_model(ld, th)
+    eng.ei_step(3)
+    full = [eng.get_time_mean(h) for h in range(4)]
+    eng.set_hypers(hypers); eng.set_time_model(ld, th)
+    eng.ei_step(3 | 8)
+    only = [eng.get_time_mean(h) for h in range(4)]
+    assert all(np.array_equal(a, b) for a, b in zip(full, only))
+    with pytest.raises(ValueError):
+        eng.best()
+    with pytest.raises(ValueError):
+        eng.ei_step(8)                      # needs PER_SEC | KEEP_MOMENTS
+    eng.set_candidates(cand[:100])
+    with pytest.raises(ValueError):
+        eng.get_time_mean(0)
