@@ -118,6 +118,65 @@ __device__ __forceinline__ void factor16<5>(d4& C, d4& Xout, d4& U, int lane, in
     }
 }
 
+
+// V7 = V5 with the NEXT pair's pivot block (d0, e, d1) formed ahead of the MFMA that updates it: the three entries by the
+// two rounded fmas the matrix pipe applies to them (k-slot order), on v_readlane values of the two columns just formed --
+// the scalar recurrence of pair j + 2 then starts without waiting for the MFMA of pair j to retire.
+template <>
+__device__ __forceinline__ void factor16<7>(d4& C, d4& Xout, d4& U, int lane, int& bad)
+{
+    const int c = lane & 15, q = lane >> 4;
+    d4 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { X[r] = (q + 4 * r == c) ? 1.0 : 0.0; U[r] = 0.0; Xout[r] = 0.0; }
+    double d0 = readlane_f64(C[0], 0), e = readlane_f64(C[0], 1), d1 = readlane_f64(C[0], 1 + 16);
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const int qa = j & 3, rj = j >> 2;
+        const bool ga = (q == qa), gb = (q == qa + 1);
+        if (!(d0 > 0.0)) { if (!bad) bad = j + 1; d0 = 1.0; }
+        const double y0 = __builtin_amdgcn_rsq(d0);
+        const double e0 = fma(-d0 * y0, y0, 1.0);
+        const double rinv0 = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+        const double l10 = e * rinv0;
+        double d1p = fma(-l10, l10, d1);
+        if (!(d1p > 0.0)) { if (!bad) bad = j + 2; d1p = 1.0; }
+        const double y1 = __builtin_amdgcn_rsq(d1p);
+        const double e1 = fma(-d1p * y1, y1, 1.0);
+        const double rinv1 = fma(y1 * e1, fma(0.375, e1, 0.5), y1);
+        const double l0 = C[rj] * rinv0;
+        const double x0 = X[rj] * rinv0;
+        const double l0n = from_even_row(l0), x0n = from_even_row(x0);
+        const double l1 = fma(-l10, l0n, C[rj]) * rinv1;
+        const double x1 = fma(-l10, x0n, X[rj]) * rinv1;
+        double nd0 = 0.0, ne = 0.0, nd1 = 0.0;
+        if (j + 2 < 16) {
+            const int jn = j + 2, qn = jn & 3, rn = jn >> 2;
+            const double a0 = readlane_f64(l0, 16 * qa + jn), a1 = readlane_f64(l0, 16 * qa + jn + 1);
+            const double b0 = readlane_f64(l1, 16 * (qa + 1) + jn), b1 = readlane_f64(l1, 16 * (qa + 1) + jn + 1);
+            const double c00 = readlane_f64(C[rn], jn + 16 * qn), c01 = readlane_f64(C[rn], jn + 1 + 16 * qn);
+            const double c11 = readlane_f64(C[rn], jn + 1 + 16 * (qn + 1));
+            nd0 = fma(-b0, b0, fma(-a0, a0, c00));
+            ne = fma(-b0, b1, fma(-a0, a1, c01));
+            nd1 = fma(-b1, b1, fma(-a1, a1, c11));
+        }
+        const double bC = ga ? l0 : (gb ? l1 : 0.0);
+        C = MFMA_F64(-bC, bC, C);
+        const double bX = ga ? x0 : (gb ? x1 : 0.0);
+        const double aX = (ga && c > j) ? -l0 : ((gb && c > j + 1) ? -l1 : 0.0);
+        X = MFMA_F64(aX, bX, X);
+        Xout[rj] = ga ? x0 : (gb ? x1 : Xout[rj]);
+        double sd0 = d0 * rinv0;
+        sd0 = fma(fma(-sd0, sd0, d0), 0.5 * rinv0, sd0);
+        double sd1 = d1p * rinv1;
+        sd1 = fma(fma(-sd1, sd1, d1p), 0.5 * rinv1, sd1);
+        const double keep0 = (c == j) ? sd0 : ((c > j) ? l0 : 0.0);
+        const double keep1 = (c == j + 1) ? sd1 : ((c > j + 1) ? l1 : 0.0);
+        U[rj] = ga ? keep0 : (gb ? keep1 : U[rj]);
+        d0 = nd0; e = ne; d1 = nd1;
+    }
+}
+
 // all-gather over the four 16-lane rows: v of row a -> out[a] in every row (one v_permlane16_swap + two v_permlane32_swap per dword)
 __device__ __forceinline__ void gather_rows(double v, double (&out)[4])
 {
@@ -144,6 +203,125 @@ __device__ __forceinline__ double sqrt_from(double d, double rinv)
     double sd = d * rinv;
     return fma(fma(-sd, sd, d), 0.5 * rinv, sd);
 }
+
+// V8 = V5 with fewer instructions per pair (the wave is bound by issue, ~100 instructions per pair, as much as by latency):
+// the inverse's MFMA takes the factor's A operand as it is (rows <= j + 1 of X are dead: nothing reads what the update does
+// to them); U and the inverse's rows are the MFMA operands themselves, picked up once per register (two pairs); the
+// diagonal's sqrt(d) refinement -- off the chain -- is done once, vectorised, after the last pivot, from the pivots kept
+// lane by lane (same formula on the same values: same bits).
+template <>
+__device__ __forceinline__ void factor16<8>(d4& C, d4& Xout, d4& U, int lane, int& bad)
+{
+    const int c = lane & 15, q = lane >> 4;
+    d4 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[r] = (q + 4 * r == c) ? 1.0 : 0.0;
+    double dvec = 1.0, bCa = 0.0, bXa = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const int qa = j & 3, rj = j >> 2;
+        const bool ga = (q == qa);
+        double d0 = readlane_f64(C[rj], j + 16 * qa);
+        const double e = readlane_f64(C[rj], j + 1 + 16 * qa);
+        const double d1 = readlane_f64(C[rj], j + 1 + 16 * (qa + 1));
+        if (!(d0 > 0.0)) { if (!bad) bad = j + 1; d0 = 1.0; }
+        const double y0 = __builtin_amdgcn_rsq(d0);
+        const double e0 = fma(-d0 * y0, y0, 1.0);
+        const double rinv0 = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+        const double l10 = e * rinv0;
+        double d1p = fma(-l10, l10, d1);
+        if (!(d1p > 0.0)) { if (!bad) bad = j + 2; d1p = 1.0; }
+        const double y1 = __builtin_amdgcn_rsq(d1p);
+        const double e1 = fma(-d1p * y1, y1, 1.0);
+        const double rinv1 = fma(y1 * e1, fma(0.375, e1, 0.5), y1);
+        const double l0 = C[rj] * rinv0;
+        const double x0 = X[rj] * rinv0;
+        const double l0n = from_even_row(l0), x0n = from_even_row(x0);
+        const double l1 = fma(-l10, l0n, C[rj]) * rinv1;
+        const double x1 = fma(-l10, x0n, X[rj]) * rinv1;
+        // groups qa / qa + 1 carry the two columns; the other two k-slots are zero
+        const bool live = (q >> 1) == (qa >> 1);
+        const double bC = live ? (ga ? l0 : l1) : 0.0;
+        const double bX = live ? (ga ? x0 : x1) : 0.0;
+        C = MFMA_F64(-bC, bC, C);
+        X = MFMA_F64(-bC, bX, X);
+        dvec = (c == j) ? d0 : ((c == j + 1) ? d1p : dvec);
+        if (qa == 0) { bCa = bC; bXa = bX; }
+        else {
+            U[rj] = (q < 2) ? bCa : bC;
+            Xout[rj] = (q < 2) ? bXa : bX;
+        }
+    }
+    // U[r] (lane (q, c)) = L[c][q + 4 r]: the column entries above, the diagonal refined to ~0.5 ulp, zeros below; the
+    // inverse's rows are zero right of the diagonal by construction (X starts as the identity)
+    const double rv = rsq_refined(dvec);
+    const double sdv = sqrt_from(dvec, rv);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = q + 4 * r;
+        U[r] = (c > row) ? U[r] : ((c == row) ? sdv : 0.0);
+    }
+}
+
+// V9 / V10: the pair's second pivot in closed form.  For the 2 x 2 pivot block [[a, b], [b, c]]: l11^2 = c - b^2 / a =
+// det / a, so 1 / l11 = sqrt(a) rsq(det) with det = fma(a, c, -b^2): the second reciprocal square root starts two levels
+// behind the first instead of behind all of it (rsq, its refinement, l10, the pivot's own fma) -- the pair's dependent chain
+// is ~13 levels instead of ~20, at ~25 cycles a level.  Not the same bits as V0 (the second column of a pair is scaled by
+// sqrt(a) rsq(det), ~2 ulp, instead of rsq(c - l10^2), ~1 ulp); same backward error.  V10: no select in front of the rsq
+// (a failed pivot is recorded, its numbers are garbage as the result is anyway).
+template <int V>
+__device__ __forceinline__ void factor16_cf(d4& C, d4& Xout, d4& U, int lane, int& bad)
+{
+    const int c = lane & 15, q = lane >> 4;
+    d4 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[r] = (q + 4 * r == c) ? 1.0 : 0.0;
+    double dvec = 1.0, bCa = 0.0, bXa = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const int qa = j & 3, rj = j >> 2;
+        const bool ga = (q == qa);
+        double a = readlane_f64(C[rj], j + 16 * qa);
+        const double b = readlane_f64(C[rj], j + 1 + 16 * qa);
+        const double cc = readlane_f64(C[rj], j + 1 + 16 * (qa + 1));
+        if (V == 9) { if (!(a > 0.0)) { if (!bad) bad = j + 1; a = 1.0; } }
+        else if (!(a > 0.0) && !bad) bad = j + 1;
+        double det = fma(a, cc, -(b * b));
+        if (V == 9) { if (!(det > 0.0)) { if (!bad) bad = j + 2; det = 1.0; } }
+        else if (!(det > 0.0) && !bad) bad = j + 2;
+        const double rinv0 = rsq_refined(a);
+        const double rdet = rsq_refined(det);
+        const double sd0 = a * rinv0;
+        const double rinv1 = sd0 * rdet;
+        const double l10 = b * rinv0;
+        const double l0 = C[rj] * rinv0;
+        const double x0 = X[rj] * rinv0;
+        const double l0n = from_even_row(l0), x0n = from_even_row(x0);
+        const double l1 = fma(-l10, l0n, C[rj]) * rinv1;
+        const double x1 = fma(-l10, x0n, X[rj]) * rinv1;
+        const bool live = (q >> 1) == (qa >> 1);
+        const double bC = live ? (ga ? l0 : l1) : 0.0;
+        const double bX = live ? (ga ? x0 : x1) : 0.0;
+        C = MFMA_F64(-bC, bC, C);
+        X = MFMA_F64(-bC, bX, X);
+        const double d1p = fma(-l10, l10, cc);        // (off the chain: the diagonal entry is the refined sqrt of this)
+        dvec = (c == j) ? a : ((c == j + 1) ? d1p : dvec);
+        if (qa == 0) { bCa = bC; bXa = bX; }
+        else {
+            U[rj] = (q < 2) ? bCa : bC;
+            Xout[rj] = (q < 2) ? bXa : bX;
+        }
+    }
+    const double rv = rsq_refined(dvec);
+    const double sdv = sqrt_from(dvec, rv);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = q + 4 * r;
+        U[r] = (c > row) ? U[r] : ((c == row) ? sdv : 0.0);
+    }
+}
+template <> __device__ __forceinline__ void factor16<9>(d4& C, d4& Xout, d4& U, int lane, int& bad) { factor16_cf<9>(C, Xout, U, lane, bad); }
+template <> __device__ __forceinline__ void factor16<10>(d4& C, d4& Xout, d4& U, int lane, int& bad) { factor16_cf<10>(C, Xout, U, lane, bad); }
 
 // V6: FOUR pivots per pair of MFMAs (all k-slots).  The four rows j .. j + 3 of the block sit in the four lane rows of one
 // register; an all-gather gives every lane the four entries of ITS column, the 4x4 pivot block comes by v_readlane, and
@@ -252,8 +430,14 @@ void run(const double* dS, double* dOut, long long* dCyc, const double* hS, cons
             if (out[(row * 16 + col) * 2] != g_ref[(row * 16 + col) * 2]) ++ndiff;
             if (col <= row && out[(row * 16 + col) * 2 + 1] != g_ref[(row * 16 + col) * 2 + 1]) ++ndiff;
         }
-    printf("%-44s %7.1f cycles / 16x16 block  = %5.1f / pivot   |U^T U - S| = %.2e   values of U / tril(X) differing from V0: %d\n", name,
-           (double)cyc / reps, (double)cyc / reps / 16, err, ndiff);
+    double errx = 0.0;     // |X U^T - I| over the lower triangle of X
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) {
+        double sx = 0.0;
+        for (int k = 0; k < 16; ++k) sx += (k <= i ? out[(i * 16 + k) * 2 + 1] : 0.0) * out[(j * 16 + k) * 2];
+        errx = fmax(errx, fabs(sx - (i == j)));
+    }
+    printf("%-44s %7.1f cycles / 16x16 block  = %5.1f / pivot   |U^T U - S| = %.2e  |X L - I| = %.1e   values of U / tril(X) differing from V0: %d\n", name,
+           (double)cyc / reps, (double)cyc / reps / 16, err, errx, ndiff);
 }
 
 int main()
@@ -276,5 +460,9 @@ int main()
     run<4>(dS, dOut, dCyc, hS, "V4 factor only, raw rsq (chain floor probe)");
     run<5>(dS, dOut, dCyc, hS, "V5 factor + inverse, TWO pivots per MFMA");
     run<6>(dS, dOut, dCyc, hS, "V6 factor + inverse, FOUR pivots per MFMA");
+    run<7>(dS, dOut, dCyc, hS, "V7 = V5 + next pivot block ahead of the MFMA");
+    run<8>(dS, dOut, dCyc, hS, "V8 = V5 with fewer instructions per pair");
+    run<9>(dS, dOut, dCyc, hS, "V9 = V8, second pivot in closed form");
+    run<10>(dS, dOut, dCyc, hS, "V10 = V9 without selects before the rsq");
     return 0;
 }

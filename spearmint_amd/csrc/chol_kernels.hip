@@ -265,6 +265,28 @@ __device__ __forceinline__ void trail_tile(double* S, int ti, int tj, int b0, in
     for (int r = 0; r < 4; ++r) S[(16 * ti + g + 4 * r) * LDP + 16 * tj + li] = c4[r];
 }
 
+// the same for the tile wave 0 factors next, (t,t): the result stays in its registers (the accumulator layout is the
+// layout factor16_mfma takes; the block's place in S is rewritten by the factor before anybody reads it)
+__device__ __forceinline__ d4 trail_tile_regs(const double* S, int t, int b0, int g, int li)
+{
+    d4 c4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c4[r] = S[(16 * t + g + 4 * r) * LDP + 16 * t + li];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const double av = -lds_ld(S + (16 * t + li) * LDP + b0 + 4 * ks + g);
+        const double bv = lds_ld(S + (16 * t + li) * LDP + b0 + 4 * ks + g);
+        c4 = MFMA_F64(av, bv, c4);
+    }
+    return c4;
+}
+
+#ifdef FLOW_STAMPS   // dev (k_lean_flow's time line, below): the diagonal item's own eight stamps; 4 .. 7 from inside flow_trsm / diag_block
+__shared__ long long* s_fstamp;
+#define FSTAMP2(j) do { if (threadIdx.x == 0 && s_fstamp) s_fstamp[j] = wall_clock64(); } while (0)
+#else
+#define FSTAMP2(j)
+#endif
 #ifdef SPX_DIAG_STAMPS   // dev: phase time stamps for scripts/ubench_diag.hip
 __shared__ long long g_stamp[32];
 #define STAMP(i) do { if (threadIdx.x == 0) g_stamp[i] = clock64(); } while (0)
@@ -274,15 +296,22 @@ __shared__ long long g_stamp[32];
 // PUB: block row b of the inverse (X_b0 .. X_bb) is published to the other workgroups of the launch as soon as it is
 // complete -- write-through stores, drained, then *flag = b + 1 (after the barrier that follows the last store of the
 // row) -- so that the panel solve of this block column proceeds behind the pivots instead of behind a launch boundary.
+// direct (k_lean_flow's chain): wave 0 brings sub-block (0,0) in its registers (c0) and starts on it at once -- the other
+// waves have stored rows 16 .. 63 of the block into S, nobody has synchronised yet; the barrier that S, XT and T16 need
+// before wave 0 writes into them stands behind its first sub-block's pivots instead of in front of them.
 template <bool PUB = false>
 __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, int* info_h, int pivot_base,
                                            double* __restrict__ Lkk, size_t ldl, double* __restrict__ Dk,
-                                           double* __restrict__ diag_out = nullptr, int* flag = nullptr, int flag_base = 0)
+                                           double* __restrict__ diag_out = nullptr, int* flag = nullptr, int flag_base = 0,
+                                           bool direct = false, const d4* c0 = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     int bad = 0;
     d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};     // waves 1-3: inner sum of the last row of the inverse (column wave - 1)
+    d4 Cn = (d4){0.0, 0.0, 0.0, 0.0};     // wave 0: the sub-block of the next round, updated (phase 3)
+    __shared__ int s_pub[5];              // PUB: waves 1-3 that have drained block row b - 1 of the inverse (first used behind a barrier)
+    if (PUB && threadIdx.x < 5) s_pub[threadIdx.x] = 0;
     STAMP(0);
     if (wave > 0 && wave < 4) {
         // The inverse goes to global memory block by block from the registers of the wave that computes it; the
@@ -299,11 +328,18 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         const int b0 = 16 * b;
         double* Tb = T16 + b * 16 * 18;
         // ---- phase 1 ----
+        d4 C, X, U;
         if (wave == 0) {
-            d4 C, X, U;
+            if (b > 0) C = Cn;                                  // (from phase 3 of the round before)
+            else if (direct) C = *c0;
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[r] = S[(b0 + g + 4 * r) * LDP + b0 + li];
+                for (int r = 0; r < 4; ++r) C[r] = S[(g + 4 * r) * LDP + li];
+            }
             factor16_mfma(C, X, U, lane, bad, pivot_base + b0);
+        }
+        if (b == 0 && direct) __syncthreads();                  // everybody is done with what S, XT and T16 held before
+        if (wave == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = g + 4 * r;                      // U[row][li] = L[li][row]
@@ -312,14 +348,7 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                 XT[(b0 + li) * LDP + b0 + row] = X[r];          // XT[col][row] = X[row][col]
             }
         } else if (b > 0 && wave < 4) {
-            // trailing tiles of round b-1 other than (b,b): (ti,tj), b-1 < tj <= ti, dealt to waves 1-3
-            int idx = 0;
-            for (int ti = b; ti < 4; ++ti)
-                for (int tj = b; tj <= ti; ++tj) {
-                    if (ti == b && tj == b) continue;
-                    if ((idx++ % 3) == wave - 1) trail_tile(S, ti, tj, b0 - 16, g, li);
-                }
-            // row b-1 of the inverse: wave j + 1 owns block column j (all X_pj of a column come from one wave)
+            // row b-1 of the inverse first: wave j + 1 owns block column j (all X_pj of a column come from one wave)
             if (wave - 1 < b - 1) inv_finish<PUB>(inv_partial(S, XT, b - 1, wave - 1, g, li), XT, T16, Dk, b - 1, wave - 1, g, li);
             if (wave == 3) {
                 // the diagonal block of row b-1 of the inverse, from T16 to global memory -- here, where waves 1-3 have
@@ -331,15 +360,26 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
                     dk_store<PUB>(Dk + (b0 - 16 + g + 4 * r) * NB + b0 - 16 + li, Tp[(g + 4 * r) * 18 + li]);
                 if (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            // block row b - 1 of the inverse is complete once the three waves' stores are drained: the LAST of them to get
+            // here publishes rows 0 .. b - 1 -- now, while wave 0 is still busy with sub-block b, not behind the barrier that
+            // ends its pivots (the solve that follows this block in k_lean_flow's chain is a quarter behind otherwise)
+            if (PUB && lane == 0 && __hip_atomic_fetch_add(s_pub + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2)
+                __hip_atomic_store(flag, flag_base + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // trailing tiles of round b-1 other than (b,b): (ti,tj), b-1 < tj <= ti, dealt to waves 1-3
+            int idx = 0;
+            for (int ti = b; ti < 4; ++ti)
+                for (int tj = b; tj <= ti; ++tj) {
+                    if (ti == b && tj == b) continue;
+                    if ((idx++ % 3) == wave - 1) trail_tile(S, ti, tj, b0 - 16, g, li);
+                }
             // while wave 0 factors the last sub-block: the inner sum of the LAST row, so that only the product
             // with Linv16_3 is left behind the last pivot (reads this wave's own XT stores: same wave, in order)
             if (b == 3) t4 = inv_partial(S, XT, 3, wave - 1, g, li);
         }
         STAMP(1 + 4 * b);
+        if (PUB && b == 0) FSTAMP2(7);
         __syncthreads();
         STAMP(2 + 4 * b);
-        // block row b - 1 of the inverse is complete and drained: publish rows 0 .. b - 1
-        if (PUB && b >= 1 && threadIdx.x == 192) __hip_atomic_store(flag, flag_base + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- phase 2: sub-panel, rows of tile ti = b+1+wave: P <- P Linv16^T ----
         {
             const int ti = b + 1 + wave;
@@ -358,7 +398,7 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         if (b < 3) __syncthreads();   // round 3 has no sub-panel: nothing was written
         STAMP(3 + 4 * b);
         // ---- phase 3: the one trailing tile the next factorisation needs (its operands are wave 0's own) ----
-        if (wave == 0 && b < 3) trail_tile(S, b + 1, b + 1, b0, g, li);
+        if (wave == 0 && b < 3) Cn = trail_tile_regs(S, b + 1, b0, g, li);
         STAMP(4 + 4 * b);
     }
     if (wave == 0 && lane == 0 && bad) {
@@ -378,9 +418,10 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
         for (int r = 0; r < 4; ++r) dk_store<PUB>(Dk + (48 + g + 4 * r) * NB + 48 + li, Tp[(g + 4 * r) * 18 + li]);
     }
     if (wave > 0 && wave < 4) inv_finish<PUB>(t4, XT, T16, Dk, 3, wave - 1, g, li);
-    if (PUB) {   // the last block row
+    if (PUB) {   // the last block row (inv_finish drained this wave's stores)
+        if (wave > 0 && wave < 4 && lane == 0 && __hip_atomic_fetch_add(s_pub + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2)
+            __hip_atomic_store(flag, flag_base + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (threadIdx.x == 192) __hip_atomic_store(flag, flag_base + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     STAMP(17);
     // L_kk (upper part zero), 16 bytes per lane (S is complete since the last barrier); the log-likelihood path
@@ -816,11 +857,16 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 #define FLOW_SPIN_LIMIT (1 << 20)
 #ifdef FLOW_STAMPS   // dev (make FLOW_STAMPS=1; scripts/dev/flow_timeline.py): wall-clock stamps of every diagonal item,
                      // [draw][column][4] = item start, history done, diagonal block start, diagonal block end
-__device__ long long g_flow_stamps[32 * 64 * 4];
+__device__ long long g_flow_stamps[32 * 64 * 8];
 extern "C" void spx_dev_flow_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_stamps), sizeof(g_flow_stamps)); }
-#define FSTAMP(h, c, j) do { if (threadIdx.x == 0 && (h) < 32) g_flow_stamps[((h) * 64 + (c)) * 4 + (j)] = wall_clock64(); } while (0)
+// (and the shader clock at the start and the end of every diagonal block: cycles per microsecond of the launch)
+__device__ long long g_flow_clk[32 * 64 * 2];
+extern "C" void spx_dev_flow_clk(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_clk), sizeof(g_flow_clk)); }
+#define FCLK(h, c, j) do { if (threadIdx.x == 0 && (h) < 32) g_flow_clk[((h) * 64 + (c)) * 2 + (j)] = clock64(); } while (0)
+#define FSTAMP(h, c, j) do { if (threadIdx.x == 0 && (h) < 32) g_flow_stamps[((h) * 64 + (c)) * 8 + (j)] = wall_clock64(); } while (0)
 #else
 #define FSTAMP(h, c, j)
+#define FCLK(h, c, j)
 #endif
 #define FLOW_BATCH 8        // history steps looked at per poll (3 flags each: 24 lanes)
 
@@ -903,6 +949,18 @@ __device__ __forceinline__ int flow_wait_value(const int* f, int want, int* info
     return *s_val;
 }
 
+// a1 -= X X^T for the 16 columns of the solve held in Q ([64][18]): the wave's row block against the first NTL row blocks
+template <int NTL>
+__device__ __forceinline__ void syrk_quarter(const double* Q, d4 (&a1)[4], int wave, int g, int li)
+{
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) {
+        const double a = -lds_ld(Q + (16 * wave + li) * 18 + k0 + g);
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) a1[nt] = MFMA_F64(a, lds_ld(Q + (16 * nt + li) * 18 + k0 + g), a1[nt]);
+    }
+}
+
 // rows 16 b .. 16 b + 15 of Dinv_col, columns 0 .. 16 b + 15: b + 1 values per thread, past the L1
 __device__ __forceinline__ void dinv_rows_load(const double* __restrict__ Dk, int b, double (&dv)[4])
 {
@@ -929,6 +987,7 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
     double dv[4], dn[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
+        if (DIAG && b == 3) FSTAMP2(4);
         if (b >= have) {
             have = flow_wait_value(dflag, 8 * gen + b + 1, info_h, s_val) - 8 * gen;
             dinv_rows_load(Dk, b, dv);
@@ -943,6 +1002,7 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
                 B[(16 * b + e / (16 * (b + 1))) * LDP + e % (16 * (b + 1))] = dv[m];
             }
         __syncthreads();
+        if (DIAG && b == 3) FSTAMP2(5);
         if (b + 1 < 4 && b + 1 < have) dinv_rows_load(Dk, b + 1, dn);
         out[b] = (d4){0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < 16 * (b + 1); k0 += 4)
@@ -951,19 +1011,20 @@ __device__ __forceinline__ void flow_trsm(const double* R, double* B, const doub
         if (DIAG) {
             // the owner of the next diagonal block: step lo of tile (i,i), a1 -= L_i,lo L_i,lo^T, follows the solve
             // quarter by quarter (k ascending per accumulator, like mma_tile_64: same bits) -- behind the last pivot
-            // of the block above there is a quarter of a solve and a quarter of a product, not a whole one
+            // of the block above there is a quarter of a solve and a quarter of a product, not a whole one.  Only the
+            // blocks on and below the diagonal: diag_block reads nothing above it.  Wave 0 -- which factors sub-block
+            // (0,0) next -- needs its own rows of Q and nothing else: its block goes first, in front of the barrier.
 #pragma unroll
             for (int r = 0; r < 4; ++r) Q[(16 * wave + g + 4 * r) * 18 + li] = out[b][r];
+            if (wave == 0) syrk_quarter<1>(Q, a1, wave, g, li);
             __syncthreads();
-#pragma unroll
-            for (int k0 = 0; k0 < 16; k0 += 4) {
-                const double a = -lds_ld(Q + (16 * wave + li) * 18 + k0 + g);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) a1[nt] = MFMA_F64(a, lds_ld(Q + (16 * nt + li) * 18 + k0 + g), a1[nt]);
-            }
+            if (wave == 1) syrk_quarter<2>(Q, a1, wave, g, li);
+            else if (wave == 2) syrk_quarter<3>(Q, a1, wave, g, li);
+            else if (wave == 3) syrk_quarter<4>(Q, a1, wave, g, li);
             if (b < 3) __syncthreads();    // Q is rewritten by the next quarter (which may not wait any more)
         }
     }
+    if (DIAG) FSTAMP2(6);
 }
 
 // one history step of a chunk: a0 -= L_i,k L_lo,k^T, a1 -= L_i,k L_hi,k^T (DIAG: L_hi,k is L_i,k).  In: tA = L_i,k and
@@ -1101,6 +1162,10 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
     const bool two = lo >= 0;
     __shared__ int s_n, s_val;
     d4 a0[4], a1[4], st[4];
+#ifdef FLOW_STAMPS
+    if (threadIdx.x == 0) s_fstamp = (DIAG && h < 32) ? g_flow_stamps + ((size_t)h * 64 + i) * 8 : nullptr;
+    __syncthreads();
+#endif
     if (DIAG) FSTAMP(h, i, 0);
     if (!DIAG) { flow_yield(busy); __syncthreads(); }
     if (cov.Xs && !is_rhs) {
@@ -1180,15 +1245,23 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
     }
     // ---- 3. tile (i, hi) ----
     if (!DIAG) flow_yield(busy);
-    acc_tile_to_lds(a1, A, wave, g, li);
-    __syncthreads();
+    if (!DIAG) {
+        acc_tile_to_lds(a1, A, wave, g, li);
+        __syncthreads();
+    } else if (wave != 0) {
+        // (wave 0 starts on sub-block (0,0) from its registers -- diag_block, direct; every reader of A's and T16's earlier
+        // contents is behind a barrier of flow_trsm's)
+        acc_tile_to_lds(a1, A, wave, g, li);
+    }
     if (DIAG) FSTAMP(h, i, 2);
+    if (DIAG) FCLK(h, i, 0);
     if (DIAG) {
         // (the EI path keeps L_ii -- row-major in its tile's place -- for spx_get_factor; the log-likelihood path only its diagonal)
         diag_block<true>(A, B, T16, info_h, i * NB, diag_out ? nullptr : row + (size_t)i * LEAN_TILE, NB, Dh + (size_t)i * NB * NB, diag_out,
-                         df + i, 8 * gen);
+                         df + i, 8 * gen, true, &a1[0]);
         if (busy && threadIdx.x == 0) atomicAdd(busy, -1);
         FSTAMP(h, i, 3);
+        FCLK(h, i, 1);
     } else {
         flow_trsm<false>(A, B, Dh + (size_t)hi * NB * NB, df + hi, gen, info_h, &s_val, st, row + (size_t)hi * LEAN_TILE, T16, a1, wave, g, li);
         drain_stores();
