@@ -119,6 +119,54 @@ __device__ __forceinline__ void factor16<5>(d4& C, d4& Xout, d4& U, int lane, in
 }
 
 
+// V11 = V5 without the selects in front of the two rsq (a failed pivot is recorded; its draw's numbers are NaN instead of finite garbage)
+template <>
+__device__ __forceinline__ void factor16<11>(d4& C, d4& Xout, d4& U, int lane, int& bad)
+{
+    const int c = lane & 15, q = lane >> 4;
+    d4 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { X[r] = (q + 4 * r == c) ? 1.0 : 0.0; U[r] = 0.0; Xout[r] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const int qa = j & 3, rj = j >> 2;
+        const bool ga = (q == qa), gb = (q == qa + 1);
+        double d0 = readlane_f64(C[rj], j + 16 * qa);
+        const double e = readlane_f64(C[rj], j + 1 + 16 * qa);
+        const double d1 = readlane_f64(C[rj], j + 1 + 16 * (qa + 1));
+        if (!(d0 > 0.0) && !bad) bad = j + 1;
+        const double y0 = __builtin_amdgcn_rsq(d0);
+        const double e0 = fma(-d0 * y0, y0, 1.0);
+        const double rinv0 = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+        const double l10 = e * rinv0;
+        double d1p = fma(-l10, l10, d1);
+        if (!(d1p > 0.0) && !bad) bad = j + 2;
+        const double y1 = __builtin_amdgcn_rsq(d1p);
+        const double e1 = fma(-d1p * y1, y1, 1.0);
+        const double rinv1 = fma(y1 * e1, fma(0.375, e1, 0.5), y1);
+        const double l0 = C[rj] * rinv0;                 // (meaningful in group qa: column j of L)
+        const double x0 = X[rj] * rinv0;                 // (group qa: row j of the inverse, final)
+        const double l0n = from_even_row(l0), x0n = from_even_row(x0);
+        const double l1 = fma(-l10, l0n, C[rj]) * rinv1; // (group qa + 1: column j + 1 of L)
+        const double x1 = fma(-l10, x0n, X[rj]) * rinv1;
+        const double bC = ga ? l0 : (gb ? l1 : 0.0);
+        C = MFMA_F64(-bC, bC, C);
+        const double bX = ga ? x0 : (gb ? x1 : 0.0);
+        const double aX = (ga && c > j) ? -l0 : ((gb && c > j + 1) ? -l1 : 0.0);
+        X = MFMA_F64(aX, bX, X);
+        Xout[rj] = ga ? x0 : (gb ? x1 : Xout[rj]);
+        double sd0 = d0 * rinv0;
+        sd0 = fma(fma(-sd0, sd0, d0), 0.5 * rinv0, sd0);
+        double sd1 = d1p * rinv1;
+        sd1 = fma(fma(-sd1, sd1, d1p), 0.5 * rinv1, sd1);
+        const double keep0 = (c == j) ? sd0 : ((c > j) ? l0 : 0.0);
+        const double keep1 = (c == j + 1) ? sd1 : ((c > j + 1) ? l1 : 0.0);
+        U[rj] = ga ? keep0 : (gb ? keep1 : U[rj]);
+    }
+}
+
+
+
 // V7 = V5 with the NEXT pair's pivot block (d0, e, d1) formed ahead of the MFMA that updates it: the three entries by the
 // two rounded fmas the matrix pipe applies to them (k-slot order), on v_readlane values of the two columns just formed --
 // the scalar recurrence of pair j + 2 then starts without waiting for the MFMA of pair j to retire.
@@ -464,5 +512,6 @@ int main()
     run<8>(dS, dOut, dCyc, hS, "V8 = V5 with fewer instructions per pair");
     run<9>(dS, dOut, dCyc, hS, "V9 = V8, second pivot in closed form");
     run<10>(dS, dOut, dCyc, hS, "V10 = V9 without selects before the rsq");
+    run<11>(dS, dOut, dCyc, hS, "V11 = V5 without selects before the rsq");
     return 0;
 }
