@@ -452,6 +452,97 @@ __global__ void bench(const double* S, double* out, long long* cyc, int reps)
     if (lane == 0) out[512] = acc + bad;
 }
 
+
+// V12: the inverse on a HELPER wave (another SIMD of the CU: scripts/ubench_neigh.hip shows that it does not slow the chain wave).
+// The chain wave (wave 0) runs V5 without anything that belongs to X and posts, per pair, the MFMA operand bC (one double per
+// lane) and the three scalars (rinv0, rinv1, l10) in an LDS mailbox, a sequence word last; the helper (wave 1) polls the word,
+// forms x0, x1 and the inverse's rank-2 MFMA exactly as V5 does.  Timed: the chain wave alone, and until the helper is done too.
+__global__ void bench_two(const double* S, double* out, long long* cyc, int reps)
+{
+    __shared__ double mb_vec[8][64];
+    __shared__ double mb_sc[8][4];
+    __shared__ volatile int mb_seq[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    d4 C0;
+    for (int r = 0; r < 4; ++r) C0[r] = S[(q + 4 * r) * 16 + c];
+    if (threadIdx.x < 8) mb_seq[threadIdx.x] = 0;
+    __syncthreads();
+    d4 C, X, U, Xout;
+    int bad = 0;
+    double acc = 0.0;
+    long long t0 = clock64(), t1 = 0;
+    for (int it = 0; it < reps; ++it) {
+        const int tag = it + 1;
+        if (wave == 0) {
+            C = C0;
+            C[0] += acc * 1e-300;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) U[r] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const int qa = j & 3, rj = j >> 2;
+                const bool ga = (q == qa), gb = (q == qa + 1);
+                double d0 = readlane_f64(C[rj], j + 16 * qa);
+                const double e = readlane_f64(C[rj], j + 1 + 16 * qa);
+                const double d1 = readlane_f64(C[rj], j + 1 + 16 * (qa + 1));
+                if (!(d0 > 0.0)) { if (!bad) bad = j + 1; d0 = 1.0; }
+                const double y0 = __builtin_amdgcn_rsq(d0);
+                const double e0 = fma(-d0 * y0, y0, 1.0);
+                const double rinv0 = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+                const double l10 = e * rinv0;
+                double d1p = fma(-l10, l10, d1);
+                if (!(d1p > 0.0)) { if (!bad) bad = j + 2; d1p = 1.0; }
+                const double y1 = __builtin_amdgcn_rsq(d1p);
+                const double e1 = fma(-d1p * y1, y1, 1.0);
+                const double rinv1 = fma(y1 * e1, fma(0.375, e1, 0.5), y1);
+                const double l0 = C[rj] * rinv0;
+                const double l0n = from_even_row(l0);
+                const double l1 = fma(-l10, l0n, C[rj]) * rinv1;
+                const double bC = ga ? l0 : (gb ? l1 : 0.0);
+                mb_vec[j >> 1][lane] = bC;
+                if (lane < 3) mb_sc[j >> 1][lane] = (lane == 0) ? rinv0 : ((lane == 1) ? rinv1 : l10);
+                asm volatile("" ::: "memory");      // (a wave's LDS operations are served in order: no wait between the data and the word)
+                if (lane == 0) mb_seq[j >> 1] = tag;
+                C = MFMA_F64(-bC, bC, C);
+                double sd0 = d0 * rinv0;
+                sd0 = fma(fma(-sd0, sd0, d0), 0.5 * rinv0, sd0);
+                double sd1 = d1p * rinv1;
+                sd1 = fma(fma(-sd1, sd1, d1p), 0.5 * rinv1, sd1);
+                const double keep0 = (c == j) ? sd0 : ((c > j) ? l0 : 0.0);
+                const double keep1 = (c == j + 1) ? sd1 : ((c > j + 1) ? l1 : 0.0);
+                U[rj] = ga ? keep0 : (gb ? keep1 : U[rj]);
+            }
+            acc += U[3];
+            if (it == reps - 1) t1 = clock64();
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { X[r] = (q + 4 * r == c) ? 1.0 : 0.0; Xout[r] = 0.0; }
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const int qa = j & 3, rj = j >> 2, p = j >> 1;
+                const bool ga = (q == qa), gb = (q == qa + 1);
+                while (mb_seq[p] != tag) { }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const double bC = mb_vec[p][lane];
+                const double rinv0 = mb_sc[p][0], rinv1 = mb_sc[p][1], l10 = mb_sc[p][2];
+                const double x0 = X[rj] * rinv0;
+                const double x0n = from_even_row(x0);
+                const double x1 = fma(-l10, x0n, X[rj]) * rinv1;
+                const double bX = ga ? x0 : (gb ? x1 : 0.0);
+                const double aX = (ga && c > j) ? -bC : ((gb && c > j + 1) ? -bC : 0.0);
+                X = MFMA_F64(aX, bX, X);
+                Xout[rj] = ga ? x0 : (gb ? x1 : Xout[rj]);
+            }
+        }
+        __syncthreads();       // (the end of the phase: both waves done)
+    }
+    long long t2 = clock64();
+    if (threadIdx.x == 0) { cyc[0] = t2 - t0; cyc[1] = t1; }
+    if (wave == 0) for (int r = 0; r < 4; ++r) out[((q + 4 * r) * 16 + c) * 2 + 0] = U[r];
+    if (wave == 1) for (int r = 0; r < 4; ++r) out[((q + 4 * r) * 16 + c) * 2 + 1] = Xout[r];
+    if (threadIdx.x == 0) out[512] = acc + bad;
+}
+
 static double g_ref[513];
 template <int V>
 void run(const double* dS, double* dOut, long long* dCyc, const double* hS, const char* name)
@@ -513,5 +604,23 @@ int main()
     run<9>(dS, dOut, dCyc, hS, "V9 = V8, second pivot in closed form");
     run<10>(dS, dOut, dCyc, hS, "V10 = V9 without selects before the rsq");
     run<11>(dS, dOut, dCyc, hS, "V11 = V5 without selects before the rsq");
+    {
+        const int reps = 200;
+        long long* dC2; hipMalloc(&dC2, 16);
+        hipLaunchKernelGGL(bench_two, dim3(1), dim3(128), 0, 0, dS, dOut, dC2, reps);
+        hipLaunchKernelGGL(bench_two, dim3(1), dim3(128), 0, 0, dS, dOut, dC2, reps);
+        hipDeviceSynchronize();
+        long long cy[2]; double out[513];
+        hipMemcpy(cy, dC2, 16, hipMemcpyDeviceToHost);
+        hipMemcpy(out, dOut, sizeof out, hipMemcpyDeviceToHost);
+        int ndiff = 0;
+        for (int row = 0; row < 16; ++row)
+            for (int col = 0; col < 16; ++col) {
+                if (out[(row * 16 + col) * 2] != g_ref[(row * 16 + col) * 2]) ++ndiff;
+                if (col <= row && out[(row * 16 + col) * 2 + 1] != g_ref[(row * 16 + col) * 2 + 1]) ++ndiff;
+            }
+        printf("V12 inverse on a helper wave (LDS mailbox)   %7.1f cycles / 16x16 block incl. the barrier that ends the phase = %5.1f / pivot   values of U / tril(X) differing from V0: %d\n",
+               (double)cy[0] / reps, (double)cy[0] / reps / 16, ndiff);
+    }
     return 0;
 }
