@@ -2,8 +2,13 @@
 """bench.py -- EI-candidate evaluations / second of the GP-EI hot path on MI355X.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (N > 1, no launcher: starts its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+Whichever way it is started, the JSON line's `n_gpus` is the number of ranks that TOOK PART in the collective
+(`ranks_seen`: the number of 16-byte records the all-gather returned) and the run fails instead of printing a line
+whose `n_gpus` differs from --gpus.
 
 A "step" is one full pass of the hot path over one batch of synthetic input,
 i.e. what one chooser.next() hands to the GPU: for every hyper-parameter draw
@@ -44,8 +49,12 @@ launch duration, measured with HIP events on the library's own stream over a
 second timed pass of the same steps (the headline pass runs without per-launch
 events).  `roofline_hbm` is the second regime of SURVEY.md 8(d): the HBM-side
 stages (the K(X*,X) write stream, EI finalize) against 8 TB/s.  `cpu_baseline`
-is the numpy/scipy oracle (a port of the reference chooser's compute_ei loop)
-timed on this host: 20 000 candidates, one warm-up, median of three runs.
+is the reference's OWN GPEIChooser.compute_ei loop (kind "reference": the lib2to3-converted
+S/chooser/GPEIChooser.py out of oracle/_ref/chooser_py3.zip) timed on this host's cores: 20 000
+candidates x all draws, one warm-up on a tenth of them, median of two runs; the numpy/scipy
+oracle's port of the same loop is timed once beside it (`port_value`) and the two EI matrices are
+compared bit for bit (`port_equals_reference`).  Without the archive the port alone is reported
+(kind "port").
 """
 from __future__ import print_function
 
@@ -235,6 +244,52 @@ def cpu_baseline(w, m_cpu=20000, reps=2):
     return out
 
 
+def engine_class():
+    """The engine the bench drives: spearmint_amd.engine.Engine (libspx.so, no fallback).  TEST HOOK, never set by the
+    driver: SPX_BENCH_ENGINE="module:Class" substitutes another class with the same methods, so that the launch / rank /
+    collective plumbing of this file can be exercised where no GPU exists (tests/standin_engine.py); the JSON line then
+    names it under "engine" and such a line is not a measurement."""
+    spec = os.environ.get("SPX_BENCH_ENGINE", "")
+    if not spec:
+        return Engine, "libspx"
+    import importlib
+    mod, _, cls = spec.partition(":")
+    return getattr(importlib.import_module(mod), cls or "Engine"), spec
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks ourselves --
+    re-exec this very command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one process per
+    GPU, rendezvous on 127.0.0.1, a free port) -- so that the one command the driver runs for the scaling curve yields
+    N ranks, not one.  Refuses (non-zero exit, no JSON line) when the node has fewer than N devices: a line whose
+    n_gpus differs from --gpus is never printed."""
+    n = int(args.gpus)
+    single = bool(os.environ.get("SPX_BENCH_SINGLE_DEVICE"))
+    if not single and not os.environ.get("SPX_BENCH_ENGINE"):
+        from spearmint_amd import engine as _e
+        have = _e.device_count()
+        if have < n:
+            raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s); refusing to run fewer ranks than asked "
+                             "for (SPX_BENCH_SINGLE_DEVICE=1 puts all ranks on device 0: a plumbing test, not a measurement)"
+                             % (n, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, SPX_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this pool
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def weak_problem(w, rank):
     """Observations / hyper draws (identical on every rank) and this rank's own candidate shard of
     the weak-scaling headline workload."""
@@ -300,7 +355,8 @@ def main_in_process(args):
     dt, best = run(args.steps)
     out = {
         "metric": "EI candidate evaluations per second (N_cand x mcmc_iters / wall time)",
-        "value": n * float(M) * H * args.steps / dt, "unit": "EI evals/s", "n_gpus": n, "steps": args.steps,
+        "value": n * float(M) * H * args.steps / dt, "unit": "EI evals/s", "n_gpus": n, "ranks_seen": eng.stat("ranks_seen"),
+        "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": w["desc"], "N_obs": N, "candidates_per_gpu": M, "D": D, "mcmc_iters": H,
@@ -365,6 +421,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--candidates", type=int, default=0,
+                    help="candidates per GPU of the headline instead of the workload's own (plumbing tests only: the line says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-candidates", type=int, default=20000)
     ap.add_argument("--cpu-reps", type=int, default=2)
@@ -387,14 +445,19 @@ def main():
                          "single-process Spearmint driver uses with --method-args=ndev=N")
     ap.add_argument("--devices", default="", help="with --in-process: comma-separated device ids (default 0..gpus-1)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if args.in_process:
         return main_in_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:])          # does not return: exec of the launcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line would not describe the run" % (args.gpus, world))
+    EngineCls, engine_name = engine_class()
 
     torch = None
     tdev = None
@@ -431,12 +494,15 @@ def main():
             return float(t.item())
         return dt
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.candidates:
+        w["M"] = int(args.candidates)
+        w["desc"] += " [--candidates %d per GPU: NOT the named configuration]" % w["M"]
     N, M, D, H = w["N"], w["M"], w["D"], w["H"]
     flags = FLAG_PER_SEC if w["per_sec"] else 0
     prob, comp, vals, hypers, shard = weak_problem(w, rank)
 
-    eng = Engine(local_rank)
+    eng = EngineCls(local_rank)
     eng.set_observations(comp, vals)
     eng.set_candidates(shard, index_base=rank * M)
     eng.set_hypers(hypers)
@@ -468,6 +534,7 @@ def main():
 
     attach(eng)
     rank_times = {}
+    seen = {}        # tag -> number of records the collective returned (the ranks that took part), -1 if it ever varied
 
     def all_ranks(x):
         """[x of rank 0, ..., x of rank P-1] on every rank (plumbing: per-rank step times, success flags)."""
@@ -488,7 +555,12 @@ def main():
         for _ in range(nsteps):
             e.ei_step(fl)                   # spx_factor + spx_ei_run, one host synchronisation
             idx, val = e.best()
-            out = (idx, val) if lib else spx_dist.exchange_best(val, idx, device=tdev)
+            if lib:                         # the all-gather ran inside spx_ei_step; its table had stat("ranks_seen") records
+                out, nrec = (idx, val), e.stat("ranks_seen")
+            else:
+                recs = spx_dist.exchange_records(val, idx, device=tdev)
+                out, nrec = spx_dist.pick_best(recs), len(recs)
+            seen[tag or "untagged"] = nrec if seen.get(tag or "untagged", nrec) == nrec else -1
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
         mine = time.perf_counter() - t0          # this rank's own time, before the closing barrier
@@ -564,10 +636,29 @@ def main():
                                         "bytes_per_eval": 2.0 * (Np // 128) * 8.0 + 8.0}}
 
     out = None
+    ranks_seen = seen.get("headline")
+    if ranks_seen != args.gpus:      # never a line whose n_gpus is not what was asked for and what took part
+        raise SystemExit("bench.py: --gpus %d but the collective returned %r records per step" % (args.gpus, ranks_seen))
     if rank == 0:
+        versions = {}
+        if engine_name == "libspx" and (world > 1 or lib_collective):
+            try:
+                from spearmint_amd import engine as _e
+                versions["libspx_binding"] = _e.rccl_version()          # ncclGetVersion of the librccl libspx dlopens
+            except Exception as ex:
+                versions["libspx_binding"] = "unavailable: %s" % ex
+        if world > 1 and backend == "nccl":
+            try:
+                versions["torch_backend"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as ex:
+                versions["torch_backend"] = "unavailable: %s" % ex
         out = {
             "metric": "EI candidate evaluations per second (N_cand x mcmc_iters / wall time)",
-            "value": value, "unit": "EI evals/s", "n_gpus": world, "steps": args.steps,
+            "value": value, "unit": "EI evals/s", "n_gpus": ranks_seen, "ranks_seen": ranks_seen,
+            "launcher": ("self: bench.py re-executed itself under torch.distributed.run" if os.environ.get("SPX_BENCH_SELF_LAUNCHED")
+                         else ("external torch.distributed.run" if world > 1 else "none (one rank)")),
+            "backend": (backend if world > 1 else None), "rccl_version": versions or None, "engine": engine_name,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -599,6 +690,34 @@ def main():
         out["host_inclusive_value"] = evals_per_step / min(reps)
         out["host_inclusive_ms"] = min(reps) * 1e3
         assert r[0] == best[0], "one-shot entry point and resident path disagree"
+
+    # ---- the same headline through ONE multi-device handle over this GPU (spx_create_multi: device thread, a real RCCL
+    # communicator of one rank, ncclAllGather of the record): what the n = 1 case of the in-process path costs ----------
+    if world == 1 and rank == 0 and not args.skip_extras and engine_name == "libspx":
+        try:
+            me = Engine(devices=[local_rank])
+            me.set_observations(comp, vals)
+            me.set_candidates(shard)
+            me.set_hypers(hypers)
+            if w["per_sec"]:
+                me.set_time_model(prob[4], prob[5])
+            me.ei_step(flags)
+            k_ip = max(2, min(args.steps, 5))
+            if torch is not None and torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k_ip):
+                me.ei_step(flags)
+                ip_best = me.best()
+            dt_ip = time.perf_counter() - t0
+            out["in_process_n1"] = {"value": evals_per_step * k_ip / dt_ip, "unit": "EI evals/s", "ms_per_step": dt_ip / k_ip * 1e3,
+                                    "steps": k_ip, "warmup": 1, "transport": me.transport(), "ranks_seen": me.stat("ranks_seen"),
+                                    "best_index": ip_best[0], "best_ei": ip_best[1],
+                                    "mode": "one process, one multi-device handle over this GPU (spx_create_multi + RCCL all-gather)"}
+            me.close()
+            assert ip_best == (best[0], best[1]), "multi-device handle and single-GPU handle disagree"
+        except Exception as ex:         # reported, not fatal (e.g. librccl missing on the box)
+            out["in_process_n1"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     # ---- strong scaling at the full C4 / C5 sizes -------------------------------------------------
     # With N > 1 ranks every configuration is timed with BOTH forms of the collective in the same run -- the
@@ -644,7 +763,7 @@ def main():
                 e2 = None
                 err = None
                 try:
-                    e2 = Engine(local_rank)
+                    e2 = EngineCls(local_rank)
                     e2.set_observations(scomp, svals)
                     e2.set_candidates(rows, index_base=lo)
                     e2.set_hypers(shyp)
@@ -671,7 +790,7 @@ def main():
                                 "steps": esteps, "warmup": 1, "ms_per_step": sdt / esteps * 1e3,
                                 "collective": "libspx ncclAllGather (spx_comm_attach)" if use_lib
                                               else "torch.distributed all_gather_into_tensor",
-                                "rank_step_ms": rank_times.get(key),
+                                "rank_step_ms": rank_times.get(key), "ranks_seen": seen.get(key),
                                 "config": {"workload": cfg["desc"], "N_obs": cfg["N"], "candidates_total": cfg["M"],
                                            "D": cfg["D"], "mcmc_iters": cfg["H"], "per_sec": cfg["per_sec"]},
                                 "best_index": sbest[0], "best_ei": sbest[1]}
@@ -692,7 +811,7 @@ def main():
         rows = strong_rows(cfg, scomp, svals, lo, hi)
         part = "%d draw shards x %d candidate shards" % spx_dist.grid_2d(world, args.hyper_shards)
         for key, use_lib in (("c4_2d", False), ("c4_2d_lib", True)):
-            e3 = Engine(local_rank)
+            e3 = EngineCls(local_rank)
             e3.set_observations(scomp, svals)
             e3.set_candidates(rows, index_base=lo)
             e3.set_hypers(shyp[h0:h1])

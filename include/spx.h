@@ -19,7 +19,8 @@
  *
  * Conventions: plain C, caller-owned buffers, row-major float64, int64 sizes.
  * No torch types.  Every function returns an int status: 0 = ok, <0 = error
- * (spx_last_error() gives the text).  No exceptions or exit() cross the ABI.
+ * (spx_last_error() gives the text; after a SUCCESSFUL call it may hold a text that
+ * starts with "warning:" -- see spx_get_stat).  No exceptions or exit() cross the ABI.
  * One handle = one GPU = one HIP stream; calls on a handle are serialized by
  * the caller.  All calls are synchronous unless stated.
  *
@@ -237,12 +238,18 @@ int spx_not_pd_info(spx_handle* h, int32_t* draw, int32_t* pivot);
  * executed with SPX_FLAG_TIMING.  Fills up to n entries of ms[] / launches[]
  * in the order of spx_timing_name(i); returns the number of stages.            */
 int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n);
-/* Counters a caller can poll instead of reading stderr (single-GPU handles):
- *   "flow_fallbacks"   in-launch hand-off time-outs of the one-launch factorisation (k_lean_flow) so far; after the
- *                      first one the handle factors with one launch per block column (same bits) -- never seen on a
- *                      healthy device, bounded spins make it an error path instead of a hang;
+/* Counters a caller can poll (single-GPU handles; "ranks_seen" also on a multi-device handle):
+ *   "flow_fallbacks"   in-launch hand-off time-outs of the one-launch factorisation (k_lean_flow) so far.  The call
+ *                      that saw one is repeated with one launch per block column (same bits) and returns SPX_OK with
+ *                      a WARNING left in spx_last_error() (text starts with "warning:"); the handle then keeps that
+ *                      form for "flow_rearm_after" clean factorisations (option, default 16; 0 = for good) and goes
+ *                      back to the one-launch form by itself -- or at once on spx_set_option("lean_flow", 1).  Never
+ *                      seen on a healthy device; bounded polls make it an error path instead of a hang;
+ *   "flow_rearms"      times the handle went back to the one-launch form after a fallback;
  *   "flow_enabled"     1 while the one-launch factorisation is in use;   "n_cu"  compute units of the device;
- *   "last_step_fused"  1 if the last EI pass ran as the one-kernel small-N form (N <= 128, no fantasies).        */
+ *   "last_step_fused"  1 if the last EI pass ran as a one-kernel form (no K* / beta in memory; no fantasies);
+ *   "ranks_seen"       records in the table the last exchange reduced: the ranks of the attached communicator
+ *                      (spx_comm_attach), the device slots of a multi-device handle, 1 otherwise.                  */
 int spx_get_stat(spx_handle* h, const char* name, int64_t* value);
 const char* spx_timing_name(int i);
 /* The correlation function of the GP -- the choosers' covar= argument, a function of
@@ -268,8 +275,13 @@ const char* spx_timing_name(int i);
  *   "lean_lazy"     trailing updates one (0) or two (1) block columns at a time;
  *   "lean_ps"       1: the panel solve of a block column runs inside the update launch, handed the
  *                   inverse of the diagonal block behind its pivots; 0: a launch of its own.
- * If an in-launch hand-off ever times out (its spins are bounded; never observed), the call is
- * repeated with one launch per block column and the handle stays in that form.                   */
+ * If an in-launch hand-off ever times out (its polls are bounded; never observed), the call is
+ * repeated with one launch per block column, a warning is left in spx_last_error(), and the handle
+ * stays in that form for "flow_rearm_after" clean factorisations (see spx_get_stat).
+ *   "flow_rearm_after"  clean factorisations before the one-launch form is tried again (default 16, 0 = never);
+ *   "flow_spin_limit"   polls a waiting workgroup makes before it gives up (0 = default, 2^20); tests set 1.
+ * A kernel that is refused the dynamic LDS it asks for (hipFuncSetAttribute) makes the call fail with
+ * SPX_ERR_HIP and a message naming the kernel and the size.                                       */
 int spx_set_option(spx_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -481,8 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(double* __restrict__ Lm, d
 void launch_chol_diag(hipStream_t s, double* L, double* Dinv, int* info, int Np, int k, int nh, int updated)
 {
     const size_t lds = (size_t)(3 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 112 KB > the 64 KB default
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SPX_LDS_ATTR(k_chol_diag, lds);
     hipLaunchKernelGGL(k_chol_diag, dim3(nh), dim3(256), lds, s, L, Dinv, info, Np, k, updated);
 }
 
@@ -576,8 +575,7 @@ void launch_chol_panel(hipStream_t s, double* L, const double* Dinv, int Np, int
     const int nx = nrows + pre + (rhs ? 1 : 0);
     if (nx <= 0) return;
     const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);                // 135 KB
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_panel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SPX_LDS_ATTR(k_chol_panel, lds);
     hipLaunchKernelGGL(k_chol_panel, dim3(nx, nh), dim3(256), lds, s, L, Dinv, Np, k, pre, rhs,
                        k);
 }
@@ -817,8 +815,7 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
     const int n = Np / NB - k;
     if (n <= 0) return;
     const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step_ps),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SPX_LDS_ATTR(k_lean_step_ps, lds);
     // rows k .. nblk-1 and the right-hand-side rows; k = 0 has nothing to apply: one chunk (tile (i,0)) per row
     const dim3 grid(nh, n + 1, k == 0 ? 1 : (n + LEAN_CH - 1) / LEAN_CH);
     hipLaunchKernelGGL(k_lean_step_ps, grid, dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, flags, Np, k);
@@ -855,6 +852,8 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 // CU whose products keep the matrix pipes busy: small launches ask for so much LDS that every workgroup has a CU to
 // itself; in large ones a workgroup yields while its neighbour is the next link of a chain (flow_step, cu_busy).
 #define FLOW_SPIN_LIMIT (1 << 20)
+// (the limit in force: the launch's own figure -- option flow_spin_limit, a test sets 1 to see a time-out -- or the default)
+__shared__ int s_flow_spin_limit;
 #ifdef FLOW_STAMPS   // dev (make FLOW_STAMPS=1; scripts/dev/flow_timeline.py): wall-clock stamps of every diagonal item,
                      // [draw][column][4] = item start, history done, diagonal block start, diagonal block end
 __device__ long long g_flow_stamps[32 * 64 * 8];
@@ -922,12 +921,12 @@ __device__ __forceinline__ void flow_wait(const int* f, int want, int* info_h)
 {
     if (threadIdx.x == 0) {
         int spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < FLOW_SPIN_LIMIT) {
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < s_flow_spin_limit) {
             __builtin_amdgcn_s_sleep(8);
             // somebody else gave up already: do not queue a second timeout behind the first
             if ((spins & 1023) == 0 && __hip_atomic_load(info_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) break;
         }
-        if (spins >= FLOW_SPIN_LIMIT) __hip_atomic_store(info_h, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (spins >= s_flow_spin_limit) __hip_atomic_store(info_h, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
 }
@@ -938,11 +937,11 @@ __device__ __forceinline__ int flow_wait_value(const int* f, int want, int* info
 {
     if (threadIdx.x == 0) {
         int spins = 0, v;
-        while ((v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want && ++spins < FLOW_SPIN_LIMIT) {
+        while ((v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want && ++spins < s_flow_spin_limit) {
             __builtin_amdgcn_s_sleep(8);
             if ((spins & 1023) == 0 && __hip_atomic_load(info_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) break;
         }
-        if (spins >= FLOW_SPIN_LIMIT) __hip_atomic_store(info_h, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (spins >= s_flow_spin_limit) __hip_atomic_store(info_h, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_val = v < want ? want : v;      // gave up: go on (the call fails with info < 0)
     }
     __syncthreads();
@@ -1195,7 +1194,7 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
                 const unsigned long long late = ~__ballot(f >= 8 * gen);
                 n = late ? (__ffsll((long long)late) - 1) / 3 : FLOW_BATCH;     // steps whose flags are all up, from k on
                 if (n > 0) break;
-                if (++spins >= FLOW_SPIN_LIMIT) {
+                if (++spins >= s_flow_spin_limit) {
                     if (lane == 0) __hip_atomic_store(info_h, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     n = 1;                 // gave up: go on (the call fails with info < 0)
                     break;
@@ -1274,7 +1273,8 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
                                                    int* __restrict__ info, double* __restrict__ rhs,
                                                    double* __restrict__ diagL, int* __restrict__ lflags,
                                                    int* __restrict__ dflags, unsigned* __restrict__ tickets,
-                                                   int Np, int nh, int gen, FlowCov cov, int* __restrict__ cu_busy)
+                                                   int Np, int nh, int gen, FlowCov cov, int* __restrict__ cu_busy,
+                                                   int spin_limit)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* A = smem;              // [64][LDP]
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     // (tickets[0]: the counter; tickets[1]: workgroups that are done -- the last one to leave puts both back to zero for
     // the next launch, so the host keeps no count that a failed launch could put out of step)
     __shared__ unsigned s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(tickets, 1u);
+    if (threadIdx.x == 0) { s_ticket = atomicAdd(tickets, 1u); s_flow_spin_limit = spin_limit; }
     __syncthreads();
     const int h = (int)(s_ticket % (unsigned)nh);
     const int nblk = Np / NB;
@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
                       int* dflags, unsigned* tickets, int Np, int nh, int gen, bool alone,
                       const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind,
-                      int* cu_busy)
+                      int* cu_busy, int spin_limit)
 {
     FlowCov cov{Xs, X2s, s1, htab, N, Dp, kind};
     const int nblk = Np / NB;
@@ -1353,9 +1353,9 @@ void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double
     // the attribute is per function and device, not per launch: always the larger figure, so that two handles (threads)
     // with different batch sizes cannot lower it under each other's launch.  A failure shows as a launch error
     // (checked by the caller's hipGetLastError after the launch).
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_flow), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    SPX_LDS_ATTR(k_lean_flow, 96 * 1024);
     hipLaunchKernelGGL(k_lean_flow, dim3(nh * ny), dim3(256), lds, s, Lt, Dinv, info, rhs, diagL, lflags, dflags, tickets,
-                       Np, nh, gen, cov, alone ? nullptr : cu_busy);
+                       Np, nh, gen, cov, alone ? nullptr : cu_busy, spin_limit > 0 ? spin_limit : FLOW_SPIN_LIMIT);
 }
 
 // k_lean_step2 (even k >= 2): the steps k-2 and k-1 for every remaining tile right of block column k (which needs
@@ -1426,15 +1426,13 @@ void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double
     if (n <= 0) return;
     const size_t lds = (size_t)(2 * NB * LDP + DIAG_T16_DOUBLES) * sizeof(double);   // 74.5 KB: two workgroups per CU
     if (lazy && k >= 2 && (k & 1) == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step2),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SPX_LDS_ATTR(k_lean_step2, lds);
         hipLaunchKernelGGL(k_lean_step2, dim3(nh, n + (rhs ? 1 : 0), (n + LEAN_CH - 1) / LEAN_CH), dim3(256), lds, s, Lt,
                            Dinv, info, rhs, diagL, Np, k);
         return;
     }
     const int col_only = (lazy && (k & 1)) ? 1 : 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_step),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SPX_LDS_ATTR(k_lean_step, lds);
     const dim3 grid = (k == 0) ? dim3(nh, 1, 1)
                                : dim3(nh, n + (rhs ? 1 : 0), col_only ? 1 : (n + LEAN_CH - 1) / LEAN_CH);
     hipLaunchKernelGGL(k_lean_step, grid, dim3(256), lds, s, Lt, Dinv, info, (k == 0) ? nullptr : rhs, diagL, Np, k,
@@ -1496,8 +1494,7 @@ void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs
 {
     const int nrows = Np / NB - k - 1;
     const size_t lds = (size_t)(2 * NB * LDP) * sizeof(double);   // 67.6 KB
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lean_trsm),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SPX_LDS_ATTR(k_lean_trsm, lds);
     hipLaunchKernelGGL(k_lean_trsm, dim3(nrows + 1, nh), dim3(1024), lds, s, Lt, Dinv, rhs, Np, k);
 }
 
@@ -1665,10 +1662,10 @@ void launch_trinv(hipStream_t s, const double* L, const double* Dinv, double* WT
 {
     const size_t lds = (size_t)(4 * NB * LDP) * sizeof(double);
     if (tiled) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trinv<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SPX_LDS_ATTR((k_trinv<true>), lds);
         hipLaunchKernelGGL(k_trinv<true>, dim3((Np / NB) * nh), dim3(256), lds, s, L, Dinv, WT, Np, nh);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trinv<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SPX_LDS_ATTR((k_trinv<false>), lds);
         hipLaunchKernelGGL(k_trinv<false>, dim3((Np / NB) * nh), dim3(256), lds, s, L, Dinv, WT, Np, nh);
     }
 }

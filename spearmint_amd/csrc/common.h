@@ -30,6 +30,17 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// The launchers below return nothing: a kernel that needs more dynamic LDS than the default asks for it right before its
+// launch, and a refusal is NOTED (per host thread, spx_api.hip) and reported by the API's next launch check (LAUNCHCHK) as
+// SPX_ERR_HIP naming the kernel -- not left to surface as an opaque launch failure.
+void spx_note_attr_error(const char* kernel, size_t lds_bytes, hipError_t e);
+#define SPX_LDS_ATTR(fn, bytes)                                                                                            \
+    do {                                                                                                                   \
+        hipError_t ae_ = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                             (int)(bytes));                                                                \
+        if (ae_ != hipSuccess) spx_note_attr_error(#fn, (size_t)(bytes), ae_);                                             \
+    } while (0)
+
 // ---- launchers (defined in the *.hip translation units) ---------------------
 // cov_kernels.hip
 void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp,
@@ -59,7 +70,7 @@ void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, dou
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
                       int* dflags, unsigned* tickets, int Np, int nh, int gen, bool alone,
                       const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind,
-                      int* cu_busy);
+                      int* cu_busy, int spin_limit = 0);
 void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh,
                           int* info, int* flags);
 void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int* info_out,

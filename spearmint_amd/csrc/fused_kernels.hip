@@ -240,8 +240,7 @@ static void launch_fused_kind(hipStream_t s, const double* WT, const double* gam
     dim3 grid(per, nh);
 #define SPX_FU_LAUNCH(QC_, ONE_)                                                                                          \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ei_fused128<QC_, KIND, ONE_>),                          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+        SPX_LDS_ATTR((k_ei_fused128<QC_, KIND, ONE_>), lds);                                  \
         hipLaunchKernelGGL((k_ei_fused128<QC_, KIND, ONE_>), grid, dim3(FU_THREADS), lds, s, WT, gamma, Xs, s1, Cs, s2, htab,   \
                            time_m, best, ei_draw, mom_m, mom_v, N, Mc, Dp, Q / QC_, per, c0, M, Mp);                      \
     } while (0)

@@ -36,6 +36,7 @@ SPX_HD double np_pairwise_leaf(const double* a, int64_t stride, int n)
 // live in registers): pending segments {start, length} or the marker "add the two top values", and the values.
 // n is uniform over the launch, so the walk is too.  Depth: n <= 128 << PW_DEPTH.
 #define PW_DEPTH 12
+#define NP_PAIRWISE_MAX_N (128 << PW_DEPTH)   // 524 288: the API refuses more draws / fantasies than this (spx_set_hypers)
 SPX_HD double np_pairwise(const double* a, int64_t stride, int n)
 {
 #pragma clang fp contract(off)

@@ -506,8 +506,7 @@ static void launch_gemm_variant(hipStream_t s, int grid, size_t lds, const doubl
                                 double* part_bgS)
 {
     // attribute set per launch (not cached): it is per device, and one process may drive several GPUs
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm<NW, STG, ABL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SPX_LDS_ATTR((k_predict_gemm<NW, STG, ABL>), lds);
     hipLaunchKernelGGL((k_predict_gemm<NW, STG, ABL>), dim3(grid), dim3(64 * NW), lds, s, WT, Kst, gamma, part_ss,
                        part_bg, Np, Mc, nh, ncb, nrb, part_nh, part_h0, gammaS, S, part_bgS);
 }
@@ -526,8 +525,7 @@ void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const dou
     // form only (14 = the round-1 production kernel: 4 waves, LDS-DMA staging).
     const int v = (S > 0 && variant != 0 && variant != 32) ? 14 : variant;
     if (v == 0 || v == 32) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gemm_tri),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SPX_LDS_ATTR(k_predict_gemm_tri, lds);
         hipLaunchKernelGGL(k_predict_gemm_tri, dim3(grid), dim3(256), lds, s, WT, Kst, gamma, part_ss, part_bg, Np, Mc,
                            nh, ncb, nrb, part_nh, part_h0, gammaS, S, part_bgS);
         return;

@@ -410,8 +410,7 @@ void launch_point_finish(hipStream_t s, const double* Xs, const double* hyp, con
 {
     const size_t lds = (size_t)3 * S * sizeof(double);   // up to 96 KB at S = 4096: above the 64 KB default limit
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_finish),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SPX_LDS_ATTR(k_point_finish, lds);
     hipLaunchKernelGGL(k_point_finish, dim3(nh, P), dim3(256), lds, s, Xs, hyp,
                        htab, alpha, kvec, dkdr2, tvec, zvec, x, best, out, N, Np, D, Dp, P, nh, kt, dkt, S,
                        gammaS, alphaS, bests, uvec);

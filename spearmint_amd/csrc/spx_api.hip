@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "spx_internal.h"
+#include "np_sum.h"
 
 #define SPX_VERSION 200
 
@@ -22,6 +23,21 @@ std::string& spx_err_slot()
 {
     static thread_local std::string g_err;
     return g_err;
+}
+
+std::string& spx_attr_err_slot()
+{
+    static thread_local std::string g_attr;
+    return g_attr;
+}
+
+void spx_note_attr_error(const char* kernel, size_t lds_bytes, hipError_t e)
+{
+    char buf[384];
+    snprintf(buf, sizeof buf, "hipFuncSetAttribute(%s, MaxDynamicSharedMemorySize = %zu) failed: %s", kernel, lds_bytes,
+             hipGetErrorString(e));
+    (void)hipGetLastError();
+    if (spx_attr_err_slot().empty()) spx_attr_err_slot() = buf;   // the first one is the cause
 }
 
 int spx_fail(int code, const char* fmt, ...)
@@ -46,6 +62,7 @@ static int ensure_init(spx_handle* h)
         HIPCHK(hipEventCreate(&h->ev_t1));
         HIPCHK(hipEventCreateWithFlags(&h->ev_obs, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_p0, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fac, hipEventDisableTiming));
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu > 0) h->n_cu = ncu;
         h->inited = true;
@@ -151,6 +168,7 @@ void spx_destroy(spx_handle* h)
         (void)hipEventDestroy(h->ev_t1);
         (void)hipEventDestroy(h->ev_obs);
         (void)hipEventDestroy(h->ev_p0);
+        (void)hipEventDestroy(h->ev_fac);
         (void)hipStreamDestroy(h->stream);
         (void)hipStreamDestroy(h->stream2);
     }
@@ -208,6 +226,16 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_flow")) {   // log-likelihood path: the whole factorisation as ONE data-flow launch (1, default), one launch per block column (0)
         h->lean_flow = value < 0 ? -1 : (value != 0);
+        h->flow_demoted = false;        // asking again re-arms a handle that a hand-off time-out had sent to the launches
+        h->flow_clean = 0;
+        return SPX_OK;
+    }
+    if (!strcmp(name, "flow_rearm_after")) {   // clean factorisations after a hand-off time-out before k_lean_flow is tried again (default 16; 0 = never)
+        h->flow_rearm_after = value < 0 ? 16 : (int)std::min<int64_t>(value, 1 << 30);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "flow_spin_limit")) {    // polls a k_lean_flow workgroup waits for a hand-off before it gives up (0 = default, 2^20); tests set 1 to see a time-out
+        h->flow_spin_limit = value <= 0 ? 0 : (int)std::min<int64_t>(value, 1 << 30);
         return SPX_OK;
     }
     if (!strcmp(name, "lean_ps")) {     // log-likelihood path: panel solve pipelined inside the step launch (1, default), separate launch (0)
@@ -274,6 +302,8 @@ int spx_set_hypers(spx_handle* h, const double* hypers, int32_t H)
 {
     if (h && h->multi) return spx_multi_set_hypers(h->multi, hypers, H);
     if (!h || !hypers || H < 1) return fail(SPX_ERR_ARG, "spx_set_hypers: bad arguments (H=%d)", H);
+    if (H > NP_PAIRWISE_MAX_N)   // the mean over draws walks numpy's pairwise tree with fixed-depth stacks (np_sum.h)
+        return fail(SPX_ERR_ARG, "spx_set_hypers: at most %d hyper-parameter draws (got %d)", NP_PAIRWISE_MAX_N, H);
     if (!h->have_obs) return fail(SPX_ERR_ARG, "spx_set_hypers: call spx_set_observations first");
     h->H = H;
     h->hyp_host.assign(hypers, hypers + (size_t)H * (3 + h->D));
@@ -300,6 +330,29 @@ int spx_set_time_model(spx_handle* h, const double* log_durs, const double* time
 
 // ---------------------------------------------------------------------------
 static int finish_factor(spx_handle* h, const std::vector<int>& info, bool tolerate_not_pd, bool lean);
+
+// A hand-off of k_lean_flow timed out (its polls are bounded: an error, never a hang; not seen on a healthy device -- a
+// preempted or badly oversubscribed GPU could produce one).  The call is repeated with one launch per block column -- the
+// same arithmetic, the same bits -- and the handle STAYS there for `flow_rearm_after` clean factorisations (default 16), then
+// tries the data-flow launch again (finish_factor): one bad moment does not cost a long-lived chooser process 30 % of every
+// later factorisation.  spx_set_option("lean_flow", 1) re-arms at once.  Counters: spx_get_stat("flow_fallbacks" /
+// "flow_rearms" / "flow_enabled").
+static void note_flow_timeout(spx_handle* h)
+{
+    h->flow_fallbacks += 1;
+    h->flow_demoted = true;
+    h->flow_clean = 0;
+    h->handoff_timeout = false;
+}
+// ... and the repeated call succeeded: SPX_OK, with a WARNING left in spx_last_error() (text starts with "warning:")
+static void warn_flow_fallback(spx_handle* h)
+{
+    char buf[320];
+    snprintf(buf, sizeof buf, "warning: a hand-off inside the data-flow factorisation timed out (%lld so far on this handle); "
+             "this call was repeated with one launch per block column (same results) and the handle stays there for %d "
+             "clean factorisations", (long long)h->flow_fallbacks, h->flow_rearm_after);
+    spx_err_slot() = buf;
+}
 
 // defer_sync (log-likelihood path): return with the work queued -- the caller adds its own kernel, copies `info` back
 // together with its result, synchronises ONCE and calls finish_factor (one host round trip per call instead of two)
@@ -391,7 +444,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // 1024 x 40, 0.85 -> 0.61 ms at 512 x 60): no right-hand-side rows, the diagonal blocks of L kept for spx_get_factor,
     // W = L^-1 from the tile-major factor (k_trinv<true>); every EI result stays what it was.
     const int eflow = (!lean && h->ei_flow != 0) ? 1 : 0;
-    const int flow = ((rl || eflow) && h->lean_flow != 0) ? 1 : 0;
+    const int flow = ((rl || eflow) && h->lean_flow != 0 && !h->flow_demoted) ? 1 : 0;
     const bool tiled = rl || flow;
     // (how busy the launch will be: draws x block columns^1.5 -- the residency rule below was read off scripts/dev/flow_modes.py)
     const double flow_load = (double)nh * nblk * sqrt((double)nblk);
@@ -410,7 +463,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // (measured against a launch of its own per panel solve, scripts/dev/lean_option_ab.py: -1 ... -8 % per call from N = 256
     // up -- 2048: -6.5 % at 4-12 draws, -1 % at one; 1000: -3 ... -13 %; 4096: -4 ... -5 %)
     const int want_ps = h->lean_ps >= 0 ? h->lean_ps : 1;
-    const int ps = (rl && !lazy && want_ps && h->lean_flow == 0) ? 1 : 0;   // (only without lean_flow, below)
+    const int ps = (rl && !lazy && want_ps && !flow) ? 1 : 0;   // (only without the data-flow launch, below)
     if (ps && (rc = h->ps_flags.reserve((size_t)nh * nblk * sizeof(int)))) return rc;   // zeroed by k_lean_rhs_init
     // The whole factorisation as ONE data-flow launch (k_lean_flow; option lean_flow, default on): against one launch per
     // block column -27 ... -36 % per call at N = 2048 (1-32 draws), -25 ... -34 % at N = 1000, -20 % at N = 256, -6 ... -10 %
@@ -457,7 +510,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     if (flow)
         TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, lean ? h->diagL.d() : nullptr, lflags, dflags, tickets, Np, nh, h->flow_gen, flow_alone,
                                              cov_in_flow ? h->Xs.d() : nullptr, h->X2s.d(), h->s1.d(), h->htab.d(), (int)N, Dp, dev_kind(h),
-                                             h->lean_flow_yield != 0 ? cu_busy : nullptr));
+                                             h->lean_flow_yield != 0 ? cu_busy : nullptr, h->flow_spin_limit));
     for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {
             TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));
@@ -479,6 +532,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         TIMED(ST_GAMMA_ALPHA, launch_alpha(s, h->WT.d(), h->gamma.d(), h->alpha.d(), Np, nh));
     }
     if (h->timing || !lean) HIPCHK(hipEventRecord(t1, s));
+    if (defer_sync && !lean) HIPCHK(hipEventRecord(h->ev_fac, s));   // (spx_ei_step with two streams: alpha is ready)
     if (defer_sync) return SPX_OK;
     std::vector<int> info(nh);
     HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)nh * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -489,7 +543,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
 static int finish_factor(spx_handle* h, const std::vector<int>& info, bool tolerate_not_pd, bool lean)
 {
     const int nh = (int)info.size(), H = h->H;
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     float ms = 0.f;
     if (h->timing) {
         (void)hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1);
@@ -502,6 +556,11 @@ static int finish_factor(spx_handle* h, const std::vector<int>& info, bool toler
             h->handoff_timeout = true;
             return fail(SPX_ERR_HIP, "log-likelihood factorisation: in-launch hand-off timed out (draw %d)", i);
         }
+    if (h->flow_demoted && h->flow_rearm_after > 0 && ++h->flow_clean >= h->flow_rearm_after) {
+        h->flow_demoted = false;     // the next factorisation is the data-flow launch again
+        h->flow_clean = 0;
+        h->flow_rearms += 1;
+    }
     for (int i = 0; i < nh; ++i)
         if (info[i]) { h->not_pd_draw = i; h->not_pd_pivot = info[i] - 1; break; }
     h->factored = !lean;
@@ -522,12 +581,9 @@ int spx_factor(spx_handle* h)
     h->handoff_timeout = false;
     int rc = do_factor(h, false);
     if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {   // as in spx_gp_logprob: never seen; bounded, then the launches
-        h->flow_fallbacks += 1;      // queryable: spx_get_stat("flow_fallbacks"); the message goes to stderr once per handle
-        if (h->flow_fallbacks == 1)
-            fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
-        h->lean_flow = 0;
-        h->handoff_timeout = false;
+        note_flow_timeout(h);
         rc = do_factor(h, false);
+        if (!rc) warn_flow_fallback(h);
     }
     return rc;
 }
@@ -568,7 +624,7 @@ int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, in
         launch_gamma_multi(s, h->WT.d() + (size_t)d * Np * Np, h->fantT.d() + (size_t)d * S * n,
                            h->htab.d() + (size_t)d * SPX_HT, h->gammaS.d() + (size_t)d * S * Np, (int)n, Np, S);
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     h->S = S;
     h->alphaS_valid = false;
     h->ran = false; h->ran_time = false;
@@ -604,6 +660,20 @@ static void plan_chunks(const spx_handle* h, int64_t* Mc, int* Hb)
 // home with the winner, and ONE synchronisation ends the step
 static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending);
 
+// what an EI pass refuses because of its flags alone (nmodels: 2 when a time model is / will be factored)
+static int check_run_flags(const spx_handle* h, int32_t flags, int nmodels)
+{
+    const bool per_sec = (flags & SPX_FLAG_PER_SEC) != 0;
+    const bool keep_mom = (flags & SPX_FLAG_KEEP_MOMENTS) != 0;
+    const bool time_only = (flags & SPX_FLAG_TIME_ONLY) != 0;
+    if (time_only && !(per_sec && keep_mom))
+        return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_TIME_ONLY needs SPX_FLAG_PER_SEC | SPX_FLAG_KEEP_MOMENTS");
+    if (time_only && h->comm) return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_TIME_ONLY has no winner to exchange (communicator attached)");
+    if (per_sec && nmodels != 2)
+        return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_PER_SEC needs spx_set_time_model before spx_factor");
+    return SPX_OK;
+}
+
 int spx_ei_run(spx_handle* h, int32_t flags)
 {
     if (!h) return fail(SPX_ERR_ARG, "spx_ei_run: null handle");
@@ -626,19 +696,29 @@ int spx_ei_step(spx_handle* h, int32_t flags)
         int rc = spx_factor(h);
         return rc ? rc : ei_run_impl(h, flags, false);
     }
+    // the pass's argument checks BEFORE anything is queued (ei_run_impl repeats them for spx_ei_run)
+    int rc = check_run_flags(h, flags, h->have_time ? 2 : 1);
+    if (rc) return rc;
     h->handoff_timeout = false;
-    int rc = do_factor(h, false, false, true);
+    rc = do_factor(h, false, false, true);
     if (rc) return rc;
     h->S = 0;                      // a new factorisation drops the fantasies (finish_factor), here before the run
     rc = ei_run_impl(h, flags, true);
     if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {   // as in spx_factor: bounded, then the launches
-        h->flow_fallbacks += 1;      // queryable: spx_get_stat("flow_fallbacks"); the message goes to stderr once per handle
-        if (h->flow_fallbacks == 1)
-            fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
-        h->lean_flow = 0;
-        h->handoff_timeout = false;
-        rc = spx_factor(h);
-        return rc ? rc : ei_run_impl(h, flags, false);
+        note_flow_timeout(h);
+        rc = do_factor(h, false);
+        if (!rc) rc = ei_run_impl(h, flags, false);
+        if (!rc) warn_flow_fallback(h);
+        return rc;
+    }
+    if (rc) {
+        // any other error exit of a pending step (argument checks that depend on the plan, a failed reservation, a launch
+        // error): the factorisation may still be queued -- every entry point returns with the streams idle (the pinned
+        // upload staging relies on it) and without a factor it did not check
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipGetLastError();
+        if (rc != SPX_ERR_NOT_PD) h->factored = false;
     }
     return rc;
 }
@@ -650,12 +730,9 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     const bool per_sec = (flags & SPX_FLAG_PER_SEC) != 0;
     const bool keep_mom = (flags & SPX_FLAG_KEEP_MOMENTS) != 0;
     const bool time_only = (flags & SPX_FLAG_TIME_ONLY) != 0;
-    if (time_only && !(per_sec && keep_mom))
-        return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_TIME_ONLY needs SPX_FLAG_PER_SEC | SPX_FLAG_KEEP_MOMENTS");
-    if (time_only && h->comm) return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_TIME_ONLY has no winner to exchange (communicator attached)");
-    if (per_sec && h->nmodels != 2)
-        return fail(SPX_ERR_ARG, "spx_ei_run: SPX_FLAG_PER_SEC needs spx_set_time_model before spx_factor");
-    int rc = ensure_init(h);
+    int rc = check_run_flags(h, flags, h->nmodels);
+    if (rc) return rc;
+    if ((rc = ensure_init(h))) return rc;
     if (rc) return rc;
     const int H = h->H, D = h->D, Dp = h->Dp, Np = h->Np, hs = 3 + D;
     const int64_t N = h->N, M = h->M, Mp = round_up(M, SPX_BN);
@@ -738,6 +815,11 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     const bool overlap = factor_pending && ns == 1 && h->step_overlap != 0;
     hipStream_t P0 = overlap ? h->stream2 : P;
     if (overlap) HIPCHK(hipStreamWaitEvent(P0, h->ev_obs, 0));
+    // Two streams (option streams = 2) in a step: the producer stream has no other order against the factorisation that is
+    // still queued on G.  Its scaling and K(X*,X) launches read x / ls, the row norms and the hyper table (written by the
+    // factorisation's first kernel: ev_obs); a time model's predicted durations read alpha of the duration GP -- the END of
+    // the factorisation (ev_fac).
+    if (factor_pending && ns == 2) HIPCHK(hipStreamWaitEvent(P, per_sec ? h->ev_fac : h->ev_obs, 0));
     int item = 0, chunk = 0;
     for (int64_t c0 = 0; c0 < Mp; c0 += Mc, ++chunk) {
         const int mc = (int)std::min<int64_t>(Mc, Mp - c0);       // multiple of 128
@@ -825,7 +907,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     });
     HIPCHK(hipEventRecord(t1, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     h->best_val = mirror[0];
     h->best_idx = ((const int64_t*)mirror)[1];
     if (factor_pending) {
@@ -1053,12 +1135,9 @@ int spx_gp_logprob(spx_handle* h, double* out)
     if (rc == SPX_ERR_HIP && h->handoff_timeout && h->flow_used) {
         // never seen on a healthy device; if the one-launch data flow ever stalls (its spins are bounded), the call is
         // repeated with one launch per block column -- same kernels' arithmetic, same bits -- and the handle stays there
-        h->flow_fallbacks += 1;      // queryable: spx_get_stat("flow_fallbacks"); the message goes to stderr once per handle
-        if (h->flow_fallbacks == 1)
-            fprintf(stderr, "spx: data-flow factorisation timed out; falling back to one launch per block column for this handle\n");
-        h->lean_flow = 0;
-        h->handoff_timeout = false;
+        note_flow_timeout(h);
         rc = gp_logprob_once(h, out);
+        if (!rc) warn_flow_fallback(h);
     }
     return rc;
 }
@@ -1148,7 +1227,7 @@ int spx_sobol_grid(spx_handle* h, const uint32_t* dirs, int32_t dim_max, int32_t
     HIPCHK(hipEventRecord(h->ev_t1, s));
     if (grid_out) HIPCHK(hipMemcpyAsync(grid_out, dst.p, (size_t)n * dim * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     if (kernel_ms) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
@@ -1213,7 +1292,7 @@ int spx_ei_grad_batch(spx_handle* h, const double* points, int32_t P, double* ne
     std::vector<double> out((size_t)H * P * (1 + D));
     HIPCHK(hipMemcpyAsync(out.data(), h->pt_out.p, out.size() * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     // sum over draws in draw order, as grad_optimize_ei_over_hypers does (:368-380)
     for (int p = 0; p < P; ++p) {
         double f = 0.0;
@@ -1237,9 +1316,14 @@ int spx_ei_grad(spx_handle* h, const double* point, double* neg_ei_sum, double* 
 int spx_get_stat(spx_handle* h, const char* name, int64_t* value)
 {
     if (!h || !name || !value) return fail(SPX_ERR_ARG, "spx_get_stat: null");
-    if (h->multi) return fail(SPX_ERR_ARG, "spx_get_stat: ask the per-device handles (single-GPU handles only)");
+    if (h->multi) {
+        if (!strcmp(name, "ranks_seen")) return spx_multi_stat(h->multi, name, value);
+        return fail(SPX_ERR_ARG, "spx_get_stat: ask the per-device handles (single-GPU handles only)");
+    }
     if (!strcmp(name, "flow_fallbacks")) *value = h->flow_fallbacks;          // hand-off time-outs of k_lean_flow so far
-    else if (!strcmp(name, "flow_enabled")) *value = h->lean_flow != 0;       // 0 once a time-out switched the handle to one launch per block column
+    else if (!strcmp(name, "flow_enabled")) *value = (h->lean_flow != 0 && !h->flow_demoted);   // 0 while a time-out keeps the handle on one launch per block column
+    else if (!strcmp(name, "flow_rearms")) *value = h->flow_rearms;           // times the handle went back to k_lean_flow after a fallback
+    else if (!strcmp(name, "ranks_seen")) *value = h->comm ? h->ranks_seen : 1;   // records in the table of the last all-gather (the ranks that took part)
     else if (!strcmp(name, "n_cu")) *value = h->n_cu;
     else if (!strcmp(name, "last_step_fused")) *value = h->last_fused ? 1 : 0; // the last EI pass ran k_ei_fused128
     else return fail(SPX_ERR_ARG, "spx_get_stat: unknown statistic '%s'", name);

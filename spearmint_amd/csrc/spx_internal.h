@@ -25,6 +25,19 @@ int spx_fail(int code, const char* fmt, ...);
         }                                                                                     \
     } while (0)
 
+// after a batch of launches: a noted hipFuncSetAttribute refusal first (common.h: SPX_LDS_ATTR), then the runtime's own error
+std::string& spx_attr_err_slot();
+#define LAUNCHCHK()                                                             \
+    do {                                                                        \
+        if (!spx_attr_err_slot().empty()) {                                     \
+            std::string m_ = spx_attr_err_slot();                               \
+            spx_attr_err_slot().clear();                                        \
+            (void)hipGetLastError();                                            \
+            return fail(SPX_ERR_HIP, "%s", m_.c_str());                         \
+        }                                                                       \
+        HIPCHK(hipGetLastError());                                              \
+    } while (0)
+
 // grow-only device buffer
 struct DevBuf {
     void* p = nullptr;
@@ -84,6 +97,7 @@ struct spx_handle {
                                      // work item is generated (VALU) while the GEMM of the current one runs (MFMA)
     hipEvent_t ev_sync[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // whole-stage timers (factor / ei_run)
+    hipEvent_t ev_fac = nullptr;                   // spx_ei_step: the whole factorisation (alpha included) is done (stream)
     hipEvent_t ev_obs = nullptr, ev_p0 = nullptr;  // spx_ei_step: observations scaled (stream) / first K(X*,X) ready (stream2)
 
     int64_t N = 0, M = 0, index_base = 0;
@@ -132,6 +146,12 @@ struct spx_handle {
     int lean_flow = -1;                                             // option "lean_flow": whole factorisation in one launch (k_lean_flow)
     int ei_fused = -1;                                              // option "ei_fused": N <= 128 without fantasies: the EI pass of a chunk as ONE kernel (k_ei_fused128) 1 / 0 / -1 = default (on)
     int64_t flow_fallbacks = 0;                                     // k_lean_flow hand-off time-outs that sent this handle back to one launch per block column
+    bool flow_demoted = false;                                      // ... and it is there now (until flow_rearm_after clean factorisations, or option lean_flow)
+    int flow_clean = 0;                                             // clean factorisations since the last time-out
+    int flow_rearm_after = 16;                                      // option "flow_rearm_after" (0 = never)
+    int64_t flow_rearms = 0;                                        // times the handle went back to k_lean_flow
+    int flow_spin_limit = 0;                                        // option "flow_spin_limit": polls before a hand-off gives up (0 = the kernel's default)
+    int ranks_seen = 1;                                             // records in the last all-gather's table (spx_comm_exchange)
     bool last_fused = false;                                        // the last EI pass used k_ei_fused128
     int step_overlap = -1;                                          // option "step_overlap": spx_ei_step starts the candidate side beside the factorisation 1 / 0 / -1 = default (on)
     int n_cu = 256;                                                 // compute units of the device (ensure_init)
@@ -185,6 +205,7 @@ int spx_multi_sobol_grid(spx_multi* m, const uint32_t* dirs, int32_t dim_max, in
                          int64_t skip, double* grid_out, int32_t as_candidates, double* kernel_ms);
 int spx_multi_not_pd_info(spx_multi* m, int32_t* draw, int32_t* pivot);
 int spx_multi_get_timings(spx_multi* m, double* ms, int64_t* launches, int n);
+int spx_multi_stat(spx_multi* m, const char* name, int64_t* value);
 int spx_multi_info(spx_multi* m, int32_t* n_dev, int32_t* transport, int32_t* device_ids, int32_t cap);
 // one process per GPU (spx_comm_attach): exchange this handle's record with the other ranks / drop the communicator
 int spx_comm_exchange(spx_handle* h);

@@ -264,11 +264,11 @@ __global__ void k_pick_record(const SpxRecord* __restrict__ table, int n, SpxRec
     *out = best;
 }
 
-#define NCCLCHK(m, call)                                                                         \
+#define NCCLCHK(m, name, call)                                                                   \
     do {                                                                                         \
         ncclResult_t r_ = (call);                                                                \
         if (r_ != ncclSuccess)                                                                   \
-            return fail(SPX_ERR_HIP, "%s failed: %s", #call, (m)->rccl.GetErrorString(r_));      \
+            return fail(SPX_ERR_HIP, "%s failed: %s", name, (m)->rccl.GetErrorString(r_));       \
     } while (0)
 
 static int exchange_best(spx_multi* m)
@@ -286,13 +286,13 @@ static int exchange_best(spx_multi* m)
                            (const int64_t*)k->am_out_idx.p, k->index_base, act, (SpxRecord*)k->rec_send.p);
     }
     if (m->transport == SPX_TRANSPORT_RCCL) {
-        NCCLCHK(m, m->rccl.GroupStart());
+        NCCLCHK(m, "ncclGroupStart", m->rccl.GroupStart());
         for (int i = 0; i < n; ++i) {
             spx_handle* k = m->kids[i];
-            NCCLCHK(m, m->rccl.AllGather(k->rec_send.p, k->rec_recv.p, sizeof(SpxRecord), ncclChar, m->comms[i],
+            NCCLCHK(m, "ncclAllGather", m->rccl.AllGather(k->rec_send.p, k->rec_recv.p, sizeof(SpxRecord), ncclChar, m->comms[i],
                                          k->stream));
         }
-        NCCLCHK(m, m->rccl.GroupEnd());
+        NCCLCHK(m, "ncclGroupEnd (the group of ncclAllGather / ncclAllReduce calls)", m->rccl.GroupEnd());
     } else {
         std::vector<SpxRecord> table(n);
         for (int i = 0; i < n; ++i) {
@@ -320,7 +320,7 @@ static int exchange_best(spx_multi* m)
         HIPCHK(hipSetDevice(k->device));
         HIPCHK(hipMemcpyAsync(&outs[i], k->rec_out.p, sizeof(SpxRecord), hipMemcpyDeviceToHost, k->stream));
         HIPCHK(hipStreamSynchronize(k->stream));
-        HIPCHK(hipGetLastError());
+        LAUNCHCHK();
     }
     for (int i = 1; i < n; ++i)   // every device must hold the same winner
         if (outs[i].idx != outs[0].idx || memcmp(&outs[i].val, &outs[0].val, 8))
@@ -354,13 +354,13 @@ static int exchange_sums(spx_multi* m)
             launch_sum_over_draws(k->stream, k->ei_draw.d(), k->ei_sum_full.d() + m->lo[i], k->M, round_up(k->M, SPX_BN), k->H);
     }
     if (m->transport == SPX_TRANSPORT_RCCL) {
-        NCCLCHK(m, m->rccl.GroupStart());
+        NCCLCHK(m, "ncclGroupStart", m->rccl.GroupStart());
         for (int i = 0; i < n; ++i) {
             spx_handle* k = m->kids[i];
-            NCCLCHK(m, m->rccl.AllReduce(k->ei_sum_full.p, k->ei_sum_full.p, (size_t)M, ncclFloat64, ncclSum, m->comms[i],
+            NCCLCHK(m, "ncclAllReduce", m->rccl.AllReduce(k->ei_sum_full.p, k->ei_sum_full.p, (size_t)M, ncclFloat64, ncclSum, m->comms[i],
                                          k->stream));
         }
-        NCCLCHK(m, m->rccl.GroupEnd());
+        NCCLCHK(m, "ncclGroupEnd (the group of ncclAllGather / ncclAllReduce calls)", m->rccl.GroupEnd());
     } else {
         std::vector<double> acc((size_t)M), tmp((size_t)M);
         for (int i = 0; i < n; ++i) {
@@ -391,7 +391,7 @@ static int exchange_sums(spx_multi* m)
         spx_handle* k = m->kids[i];
         HIPCHK(hipSetDevice(k->device));
         HIPCHK(hipStreamSynchronize(k->stream));
-        HIPCHK(hipGetLastError());
+        LAUNCHCHK();
     }
     for (int i = 1; i < n; ++i)   // every device must hold the same winner
         if (outs[i].idx != outs[0].idx || memcmp(&outs[i].val, &outs[0].val, 8))
@@ -483,7 +483,7 @@ static int comm_exchange_sums(spx_handle* k)
     HIPCHK(hipMemcpyAsync(&k->best_val, k->am_out_val.p, 8, hipMemcpyDeviceToHost, k->stream));
     HIPCHK(hipMemcpyAsync(&k->best_idx, k->am_out_idx.p, 8, hipMemcpyDeviceToHost, k->stream));
     HIPCHK(hipStreamSynchronize(k->stream));
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     k->best_idx -= k->index_base;   // spx_get_best adds the base back: the index is global
     k->ran_2d = true;
     return SPX_OK;
@@ -508,9 +508,10 @@ int spx_comm_exchange(spx_handle* k)
     SpxRecord out;
     HIPCHK(hipMemcpyAsync(&out, k->rec_out.p, sizeof out, hipMemcpyDeviceToHost, k->stream));
     HIPCHK(hipStreamSynchronize(k->stream));
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     k->best_idx = out.idx - k->index_base;   // spx_get_best adds the base back
     k->best_val = out.val;
+    k->ranks_seen = c->nranks;               // the table k_pick_record reduced had this many records
     return SPX_OK;
 }
 
@@ -548,8 +549,12 @@ int spx_create_multi(const int* device_ids, int32_t n_dev, spx_handle** out)
     spx_multi* m = new spx_multi();
     m->n = n_dev;
     m->devs.assign(device_ids, device_ids + n_dev);
+    // SPX_MULTI_TRANSPORT=host: records through host memory even on distinct GPUs; =rccl: the RCCL code path even for
+    // repeated device ids (a real librccl refuses such a communicator; the thread-rendezvous stand-in of the tests,
+    // tests/c/fake_rccl.hip through SPX_RCCL_LIB, accepts it -- how a 1-GPU box runs the group section with n > 1)
     const char* force = getenv("SPX_MULTI_TRANSPORT");
-    m->transport = (distinct && !(force && !strcmp(force, "host"))) ? SPX_TRANSPORT_RCCL : SPX_TRANSPORT_HOST;
+    const bool want_host = force && !strcmp(force, "host"), want_rccl = force && !strcmp(force, "rccl");
+    m->transport = ((distinct && !want_host) || want_rccl) ? SPX_TRANSPORT_RCCL : SPX_TRANSPORT_HOST;
     if (m->transport == SPX_TRANSPORT_RCCL) {
         int rc = load_rccl(&m->rccl);
         if (rc) { delete m; return rc; }
@@ -656,6 +661,12 @@ int spx_multi_info(spx_multi* m, int32_t* n_dev, int32_t* transport, int32_t* de
     if (transport) *transport = m->transport;
     for (int i = 0; device_ids && i < cap && i < m->n; ++i) device_ids[i] = m->devs[i];
     return SPX_OK;
+}
+
+int spx_multi_stat(spx_multi* m, const char* name, int64_t* value)
+{
+    if (!strcmp(name, "ranks_seen")) { *value = m->n; return SPX_OK; }   // device slots whose records the exchange reduced
+    return fail(SPX_ERR_ARG, "spx_get_stat: unknown statistic '%s' of a multi-device handle", name);
 }
 
 void spx_multi_destroy(spx_multi* m)

@@ -49,21 +49,21 @@ def pick_best(records):
     return best_i, (float(best_v) if best_i >= 0 else float("nan"))
 
 
-def exchange_best(local_value, local_index, device=None, group=None):
+def exchange_records(local_value, local_index, device=None, group=None):
     """The one collective of the path: every rank contributes its 16-byte record {best mean EI
     (float64), global index (int64)} to ONE all-gather (P x 16 bytes; RCCL over xGMI with backend
-    "nccl"), then applies the same numpy-argmax reduction to the gathered table.  Returns
-    (global_index, value), identical on every rank.  The record travels as raw bytes, so the index
-    is exact over the whole int64 range.
+    "nccl").  Returns the gathered table as a list of P (value, index) pairs in rank order -- the
+    same bytes on every rank; its length is the number of ranks that took part.  The record travels
+    as raw bytes, so the index is exact over the whole int64 range.
 
-    Without an initialised process group (single process) it is the identity."""
+    Without an initialised process group (single process) the table is this rank's own record."""
     try:
         import torch
         import torch.distributed as dist
     except ImportError:  # pragma: no cover
-        return int(local_index), float(local_value)
+        return [(float(local_value), int(local_index))]
     if not (dist.is_available() and dist.is_initialized()):
-        return int(local_index), float(local_value)
+        return [(float(local_value), int(local_index))]
     P = dist.get_world_size(group)
     rec = np.zeros(1, dtype=[("val", "<f8"), ("idx", "<i8")])
     rec["val"][0] = local_value
@@ -74,7 +74,13 @@ def exchange_best(local_value, local_index, device=None, group=None):
     table = torch.empty(16 * P, dtype=torch.uint8, device=mine.device)
     dist.all_gather_into_tensor(table, mine, group=group)
     got = table.cpu().numpy().view([("val", "<f8"), ("idx", "<i8")])
-    return pick_best([(r["val"], r["idx"]) for r in got])
+    return [(float(r["val"]), int(r["idx"])) for r in got]
+
+
+def exchange_best(local_value, local_index, device=None, group=None):
+    """exchange_records + the numpy-argmax reduction every rank applies to the gathered table:
+    (global_index, value), identical on every rank."""
+    return pick_best(exchange_records(local_value, local_index, device=device, group=group))
 
 
 allreduce_best = exchange_best   # round-1 name

@@ -442,8 +442,15 @@ class Engine(object):
         self._check(self._lib.spx_not_pd_info(self._h, ctypes.byref(d), ctypes.byref(p)))
         return int(d.value), int(p.value)
 
+    def last_warning(self):
+        """The warning a SUCCESSFUL call left in spx_last_error() (text starting with "warning:", include/spx.h:
+        spx_get_stat), or None."""
+        msg = self._lib.spx_last_error()
+        msg = msg.decode("utf-8", "replace") if isinstance(msg, bytes) else str(msg or "")
+        return msg if msg.startswith("warning:") else None
+
     def stat(self, name):
-        """A counter of the handle: "flow_fallbacks", "flow_enabled", "n_cu", "last_step_fused" (include/spx.h: spx_get_stat)."""
+        """A counter of the handle: "flow_fallbacks", "flow_rearms", "flow_enabled", "n_cu", "last_step_fused", "ranks_seen" (include/spx.h: spx_get_stat)."""
         v = ctypes.c_int64(0)
         self._check(self._lib.spx_get_stat(self._h, name.encode("ascii"), ctypes.byref(v)))
         return int(v.value)

@@ -148,3 +148,59 @@ def test_2d_partition_allreduce_gloo_world4():
         # (the oracle's BLAS results depend on the column blocking at the 1e-12 level)
         assert np.allclose(mean, ref, rtol=1e-9, atol=1e-300) and np.isclose(val, ref[idx], rtol=1e-9)
     assert all(np.array_equal(res[0][3], r[3]) for r in res[1:])           # bit-identical on every rank
+
+
+# ---- bench.py --gpus N starts N ranks by itself ---------------------------------------------------
+def _bench(args, env=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=e, cwd=root, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=timeout)
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    return res.returncode, (json.loads(lines[-1]) if lines else None), res.stderr.decode()
+
+
+STANDIN = {"SPX_BENCH_BACKEND": "gloo", "SPX_BENCH_SINGLE_DEVICE": "1", "SPX_BENCH_ENGINE": "tests.standin_engine:Engine"}
+SMALL = ["--workload", "c2", "--candidates", "1500", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-live-traffic",
+         "--skip-extras"]
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` -- the form of the command the driver runs -- with NO launcher around it: bench.py
+    re-executes itself under torch.distributed.run, two ranks take part in the one all-gather (ranks_seen, counted from
+    the gathered table itself), and the line says n_gpus == 2.  The engine is the oracle-backed stand-in (no GPU here);
+    the GPU suite runs the same command on libspx (tests/test_gpu_d_multi.py)."""
+    import bench
+    from oracle import gp_ei_oracle as orc
+    rc, out, err = _bench(["--gpus", "2"] + SMALL, STANDIN)
+    assert rc == 0 and out is not None, err[-2000:]
+    assert out["n_gpus"] == out["ranks_seen"] == 2 and out["launcher"].startswith("self")
+    assert out["backend"] == "gloo" and out["engine"] == "tests.standin_engine:Engine"
+    assert out["config"]["candidates_per_gpu"] == 1500 and out["value"] > 0
+    # the winner over both ranks' shards == one rank over the concatenated candidates
+    w = dict(bench.WORKLOADS["c2"], M=1500)
+    _, comp, vals, hypers, s0 = bench.weak_problem(w, 0)
+    s1 = bench.weak_problem(w, 1)[4]
+    mean = np.mean(orc.ei_over_hypers(comp, np.vstack((s0, s1)), vals, hypers), axis=1)
+    # (the oracle's BLAS results depend on the column blocking at the 1e-12 level: same index, value to rounding)
+    assert out["best_index"] == int(np.argmax(mean)) and abs(out["best_ei"] - float(np.max(mean))) <= 1e-9 * float(np.max(mean))
+    # ... and the same command with --gpus 1 is one rank
+    rc1, out1, err1 = _bench(["--gpus", "1"] + SMALL, STANDIN)
+    assert rc1 == 0 and out1["n_gpus"] == out1["ranks_seen"] == 1 and out1["launcher"].startswith("none"), err1[-2000:]
+    m0 = np.mean(orc.ei_over_hypers(comp, s0, vals, hypers), axis=1)
+    assert out1["best_index"] == int(np.argmax(m0))
+
+
+def test_bench_refuses_a_line_whose_n_gpus_is_not_what_was_asked_for():
+    """--gpus 2 on a node without two devices (this container has none), or inside a world of another size: a non-zero
+    exit and NO JSON line -- never a line that says n_gpus 1."""
+    rc, out, err = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert rc != 0 and out is None and "--gpus 2" in err and "GPU" in err
+    rc, out, err = _bench(["--gpus", "2"] + SMALL, dict(STANDIN, WORLD_SIZE="1", RANK="0"))
+    assert rc != 0 and out is None and "WORLD_SIZE=1" in err

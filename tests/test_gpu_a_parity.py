@@ -13,6 +13,7 @@ import pytest
 
 from oracle import gp_ei_oracle as orc
 from spearmint_amd import dist as sd
+from spearmint_amd.engine import Engine, FLAG_PER_SEC
 from spearmint_amd.synthetic import synthetic_problem
 
 pytestmark = pytest.mark.gpu
@@ -587,6 +588,88 @@ def test_two_stream_mode_is_bit_identical(eng):
         eng.set_option("kstar_budget_bytes", 0)
     assert a[0] == b[0] and np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
     assert ap[0] == bp[0] and np.array_equal(ap[3], bp[3])
+
+
+def test_two_stream_step_waits_for_the_pending_factorisation(eng):
+    """spx_ei_step queues the factorisation on the main stream and, with option streams=2, the
+    producer stream's scaling / K(X*,X) / duration-GP launches had no order against it -- they could read x / ls, the hyper
+    table and alpha of the PREVIOUS problem.  The earlier two-stream test could not see that (the preceding one-stream
+    call had left identical data behind).  Here every call changes observations AND hyper draws, and a two-stream handle
+    is compared with a one-stream handle call by call."""
+    two = Engine(0)
+    try:
+        two.set_option("streams", 2)
+        for e in (eng, two):
+            e.set_option("kstar_budget_bytes", 384 * 1024 * 8)      # several chunks and work items
+        for rep in range(6):
+            N = 260 + 130 * (rep % 3)                                  # (the padded size changes too)
+            comp, cand, vals, hypers, log_durs, th = synthetic_problem(N, 5000, 7, 5, 710 + rep, per_sec=True)
+            a = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+            b = two.ei_grid(comp, vals, cand, hypers, want_draws=True)
+            assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3]), rep
+            ap = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+            bp = two.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+            assert ap[0] == bp[0] and ap[1] == bp[1] and np.array_equal(ap[3], bp[3]), rep
+    finally:
+        two.close()
+        eng.set_option("kstar_budget_bytes", 0)
+
+
+def test_step_argument_errors_leave_nothing_queued(eng):
+    """spx_ei_step checks its flags BEFORE it queues the factorisation, and any later error exit of a pending
+    step returns with the streams idle and without an unchecked factor."""
+    comp, cand, vals, hypers = synthetic_problem(300, 2000, 5, 4, 77)
+    eng.set_observations(comp, vals); eng.set_hypers(hypers); eng.set_candidates(cand)
+    with pytest.raises(ValueError):
+        eng.ei_step(FLAG_PER_SEC)                 # no time model
+    with pytest.raises(ValueError):
+        eng.get_factor(0)                         # nothing was factored by the refused call
+    with pytest.raises(ValueError):
+        eng.ei_step(8)                            # SPX_FLAG_TIME_ONLY alone
+    eng.ei_step(0)
+    ref = orc.ei_over_hypers(comp, cand, vals, hypers)
+    assert eng.best()[0] == orc.choose(ref)
+
+
+def test_injected_handoff_timeout_falls_back_warns_and_rearms():
+    """a hand-off time-out of the data-flow factorisation (injected: one poll instead of 2^20) makes
+    THAT call fall back to one launch per block column -- same bits, SPX_OK, a warning in spx_last_error -- keeps the handle
+    there for `flow_rearm_after` clean factorisations and then returns it to the data-flow launch by itself."""
+    comp, cand, vals, hypers = synthetic_problem(700, 3000, 6, 3, 78)
+    e = Engine(0)
+    try:
+        e.set_observations(comp, vals); e.set_hypers(hypers); e.set_candidates(cand)
+        lp = e.gp_logprob()
+        e.ei_step(0)
+        best, draws = e.best(), e.ei_draws()
+        assert e.stat("flow_enabled") == 1 and e.stat("flow_fallbacks") == 0 and e.last_warning() is None
+        e.set_option("flow_rearm_after", 3)
+        e.set_option("flow_spin_limit", 1)         # the first hand-off that is not there yet gives up
+        lp1 = e.gp_logprob()
+        assert np.array_equal(lp1, lp)             # the repeated call's result
+        assert e.stat("flow_fallbacks") == 1 and e.stat("flow_enabled") == 0
+        w = e.last_warning()
+        assert w and w.startswith("warning:") and "timed out" in w
+        e.set_option("flow_spin_limit", 0)
+        for k in range(3):                         # clean calls on the fallback form ...
+            assert e.stat("flow_enabled") == 0
+            assert np.array_equal(e.gp_logprob(), lp)
+        assert e.stat("flow_enabled") == 1 and e.stat("flow_rearms") == 1       # ... and the handle is back
+        assert np.array_equal(e.gp_logprob(), lp) and e.stat("flow_fallbacks") == 1
+        # the same through the EI step (factorisation pending behind the pass) and spx_factor
+        e.set_option("flow_spin_limit", 1)
+        e.ei_step(0)
+        assert e.stat("flow_fallbacks") == 2 and e.best() == best and np.array_equal(e.ei_draws(), draws)
+        e.set_option("lean_flow", 1)               # asking again re-arms at once
+        assert e.stat("flow_enabled") == 1
+        e.factor()
+        assert e.stat("flow_fallbacks") == 3
+        e.set_option("flow_spin_limit", 0)
+        e.set_option("lean_flow", 1)
+        e.ei_step(0)
+        assert e.stat("flow_fallbacks") == 3 and e.best() == best and np.array_equal(e.ei_draws(), draws)
+    finally:
+        e.close()
 
 
 def test_gpei_chooser_ml2_hypers_on_gpu(golden_dir, tmp_path):

@@ -217,6 +217,44 @@ def test_bench_two_ranks_equals_one_rank_over_concatenated_candidates(eng):
                                          or "communicator" in out["c4_lib"]["error"].lower())
 
 
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_with_no_launcher_starts_two_ranks_on_libspx(eng):
+    """`python bench.py --gpus 2` -- no torch.distributed.run around it, the form of the driver's
+    command -- starts its own two ranks (here both on GPU 0, gloo), the line says n_gpus == ranks_seen == 2 (counted from
+    the gathered table), and the winners are those of one rank over the same candidates."""
+    env = dict(os.environ, SPX_BENCH_BACKEND="gloo", SPX_BENCH_SINGLE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c2",
+           "--no-cpu-baseline", "--no-live-traffic", "--extra-steps", "1", "--c4-candidates", "30000", "--c5-candidates", "20000"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=850)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == out["ranks_seen"] == 2 and out["launcher"].startswith("self") and out["engine"] == "libspx"
+    w = bench.WORKLOADS["c2"]
+    _, comp, vals, hypers, s0 = bench.weak_problem(w, 0)
+    s1 = bench.weak_problem(w, 1)[4]
+    idx, val, _, _ = eng.ei_grid(comp, vals, np.vstack((s0, s1)), hypers)
+    assert (out["best_index"], out["best_ei"]) == (idx, val)
+    assert out["c4"]["ranks_seen"] == 2 and out["c5"]["ranks_seen"] == 2 and out["c4"]["n_gpus"] == 2
+    # one rank, same command: the strong-scaling grids give the same winners
+    cmd[cmd.index("--gpus") + 1] = "1"
+    res1 = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=850)
+    assert res1.returncode == 0, res1.stderr.decode()[-2000:]
+    out1 = json.loads([l for l in res1.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out1["n_gpus"] == out1["ranks_seen"] == 1 and out1["launcher"].startswith("none")
+    for name in ("c4", "c5"):
+        assert (out[name]["best_index"], out[name]["best_ei"]) == (out1[name]["best_index"], out1[name]["best_ei"])
+    # and a node with ONE GPU refuses --gpus 2 outright (no line with n_gpus 1): non-zero exit, no JSON
+    from spearmint_amd import engine as eng_mod
+    if eng_mod.device_count() < 2:
+        env2 = {k: v for k, v in env.items() if k not in ("SPX_BENCH_BACKEND", "SPX_BENCH_SINGLE_DEVICE")}
+        res2 = subprocess.run(cmd[:2] + ["--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert res2.returncode != 0 and not [l for l in res2.stdout.decode().splitlines() if l.startswith("{")]
+        assert "refusing" in res2.stderr.decode()
+
+
 # ---- spx_ei_grad_batch: the refinement objective ---------------------------------------------------
 def test_ei_grad_batch_matches_reference_golden(eng, golden_dir):
     """Value + gradient of the reference's grad_optimize_ei_over_hypers (GPEIOptChooser.py:360-525,
