@@ -244,6 +244,61 @@ def cpu_baseline(w, m_cpu=20000, reps=2):
     return out
 
 
+def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3):
+    """The cpu_baseline leg END TO END: one whole `GPEIOptChooser.next()` -- slice sampling of the
+    hyper-parameters (burn-in + mcmc_iters draws), both EI passes over the grid, the L-BFGS-B refinement of the best 20
+    candidates -- by the reference's OWN chooser (S/chooser/GPEIOptChooser.py:217-328, lib2to3-converted, numpy/scipy on this
+    host's cores, use_multiprocessing=0) and by ours on libspx, from the same seeded state at a size the reference finishes
+    (N_obs=256, 20 000 grid candidates, 8-D, mcmc_iters=10).  The two proposals must be the same point.  Ours is timed twice:
+    a cold first call (library load, HIP context, buffer allocation) and a second chooser object on the warm process."""
+    import tempfile
+    import numpy.random as npr
+    from oracle import ref_py3
+    from spearmint_amd.chooser import GPEIOptChooser as ours_mod
+    mods = ref_py3.load() if ref_py3.available() else ref_py3.load_shipped()
+    comp, cand, vals, _ = synthetic_problem(N, M, D, 1, 9)
+    grid = np.vstack((comp, cand))
+    values = np.concatenate((vals, np.full(M, np.nan)))
+    durations = np.ones(N + M)
+    complete, candidates, pending = np.arange(N), np.arange(N, N + M), np.array([], dtype=int)
+    args = "mcmc_iters=%d,burnin=%d,grid_subset=20,use_multiprocessing=0" % (mcmc_iters, burnin)
+
+    def run(mod):
+        ch = mod.init(tempfile.mkdtemp(prefix="spx_next_"), args)
+        npr.seed(seed)
+        t0 = time.time()
+        job = ch.next(grid, values, durations, candidates, pending, complete)
+        return time.time() - t0, job
+
+    def show(job):
+        return {"index": int(job[0]), "point": [float(v) for v in job[1]]} if isinstance(job, tuple) else {"index": int(job)}
+
+    cold_s, job_a = run(ours_mod)
+    warm_s, job_b = run(ours_mod)
+    out = {"what": "one GPEIOptChooser.next() call: %d burn-in + %d slice-sampled draws, two EI passes over the grid, L-BFGS-B "
+                   "refinement of 20 candidates" % (burnin, mcmc_iters),
+           "config": {"N_obs": N, "grid_candidates": M, "D": D, "chooser_args": args, "seed": seed},
+           "ours": {"cold_s": cold_s, "warm_s": warm_s, "proposal": show(job_b), "engine": "libspx (HIP, fp64)"},
+           "ours_repeatable": show(job_a) == show(job_b)}
+    if mods is None:
+        out["reference"] = None
+        return out
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    ref_s, job_r = run(mods["GPEIOptChooser"])
+    out["reference"] = {"s": ref_s, "proposal": show(job_r), "cores": int(threads), "host_cpus": os.cpu_count(),
+                        "what": "the reference's own GPEIOptChooser.next() (lib2to3-converted S/chooser/GPEIOptChooser.py, numpy/scipy)"}
+    same = isinstance(job_b, tuple) == isinstance(job_r, tuple) and show(job_b)["index"] == show(job_r)["index"]
+    if same and isinstance(job_b, tuple):
+        same = bool(np.allclose(job_b[1], job_r[1], rtol=0, atol=1e-6))
+    out["same_proposal"] = bool(same)
+    out["speedup_warm"] = ref_s / warm_s
+    return out
+
+
 def engine_class():
     """The engine the bench drives: spearmint_amd.engine.Engine (libspx.so, no fallback).  TEST HOOK, never set by the
     driver: SPX_BENCH_ENGINE="module:Class" substitutes another class with the same methods, so that the launch / rank /
@@ -424,6 +479,9 @@ def main():
     ap.add_argument("--candidates", type=int, default=0,
                     help="candidates per GPU of the headline instead of the workload's own (plumbing tests only: the line says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--next-baseline", action="store_true",
+                    help="instead of the EI-grid bench: time one whole GPEIOptChooser.next() of the reference (CPU) and of this "
+                         "library from the same seeded state (N_obs=256, 20 000 candidates, mcmc_iters=10) and print both")
     ap.add_argument("--cpu-candidates", type=int, default=20000)
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -447,6 +505,9 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.next_baseline:
+        print(json.dumps(next_baseline()))
+        return
     if args.in_process:
         return main_in_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

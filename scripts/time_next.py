@@ -1,6 +1,14 @@
-"""End-to-end GPEIOptChooser.next() wall time: host sampler/refinement vs GPU ones (dev tool)."""
+"""End-to-end GPEIOptChooser.next() wall time: host sampler/refinement vs GPU ones (dev tool);
+`python scripts/time_next.py --with-reference`: the reference's own next() beside ours (bench.next_baseline)."""
 import sys, os, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--with-reference" in sys.argv:
+    # the reference's own GPEIOptChooser.next() beside ours, same seeded state, N = 256 x 20 000 x mcmc_iters 10:
+    # bench.py's cpu_baseline leg end to end (the reference loader lives behind bench.py, not in the product)
+    import json
+    import bench
+    print(json.dumps(bench.next_baseline(), indent=1))
+    sys.exit(0)
 import numpy as np, numpy.random as npr
 from spearmint_amd.chooser import GPEIOptChooser
 from spearmint_amd.synthetic import synthetic_problem

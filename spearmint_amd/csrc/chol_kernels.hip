@@ -1572,8 +1572,8 @@ void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, 
 // computed as transposes so both stores and loads are row-contiguous:
 //   Tt[n][i'] = sum_p sum_q WT[j0+n][p0+q] L[i0+i'][p0+q]
 //   WT[j0+n][i0+i''] = - sum_{i'} Tt[n][i'] Dinv_i[i''][i']
-// WT must be zero-initialised by the caller (entries above the block diagonal
-// inside a 128-wide GEMM row block are read by the predict GEMM).
+// The zeros of WT left of the diagonal block (entries the predict GEMM reads inside its 128-wide row blocks) are written by
+// this kernel itself, by the workgroup that owns the rows: the caller does NOT clear the buffer.
 // ---------------------------------------------------------------------------
 // TILED: L in the tile-major storage of the log-likelihood path (k_lean_flow factored it): tile (i, p) at
 // (i nblk + p) * 4096 doubles, accumulator order inside

@@ -744,7 +744,14 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
         // the per-fantasy partial means are [nrb][2][S][Mc]: keep them under 2 GB (of 288: at C3 size with 100 fantasies the
         // plan's own 28 672-candidate chunks fit; the 256 MB of earlier rounds cut them to 9 856 -- 420 launch pairs of a
         // few dozen workgroups instead of 140)
-        int64_t cap = (2048ll << 20) / ((int64_t)nrb * 2 * S * 8) / SPX_BN * SPX_BN;
+        // (... of what the device has free: a smaller or fuller GPU takes smaller chunks instead of an allocation failure)
+        size_t mem_free = 0, mem_total = 0;
+        int64_t fant_budget = 2048ll << 20;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) {
+            const int64_t have = (int64_t)(mem_free / 8) + (int64_t)(h->part_bgS[0].cap + h->part_bgS[1].cap + h->scratch.cap) / 2;
+            fant_budget = std::max<int64_t>(64ll << 20, std::min<int64_t>(fant_budget, have));
+        } else (void)hipGetLastError();
+        int64_t cap = fant_budget / ((int64_t)nrb * 2 * S * 8) / SPX_BN * SPX_BN;
         if (cap < SPX_BN) cap = SPX_BN;
         if (Mc > cap) {
             const int64_t nchunks = (Mp + cap - 1) / cap;
@@ -752,7 +759,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
         }
         // ... and as many draws per launch as that leaves room for (small problems: all of them -- ten launch pairs of a
         // 20 000-candidate pass become one)
-        int64_t hb = (2048ll << 20) / ((int64_t)nrb * 2 * S * 8 * Mc);
+        int64_t hb = fant_budget / ((int64_t)nrb * 2 * S * 8 * Mc);
         if (hb > 65535 / S) hb = 65535 / S;       // (grid.y of the per-fantasy EI kernel)
         if (hb < 1) hb = 1;
         if (hb < Hb) Hb = (int)hb;

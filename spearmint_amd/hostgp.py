@@ -271,7 +271,15 @@ def fantasize_from_factor_rows(vals, hyper_row, l_rows, gamma, randn_ps):
     L = [[L_A, 0], [L21, L_S]],  L21 = (L_A^-1 B)^T  and  L_S L_S^T = C - B^T A^-1 B  (B = cov(comp, pend),
     C = pend_kappa + noise I), so   pend_m = B^T A^-1 (vals - mean) + mean = L21 gamma[:N] + mean   and
     pend_K = pend_kappa - B^T A^-1 B = L_S L_S^T - noise I   -- GPEIChooser.py:229-236 without the two
-    O(N^2 P) solves against the N x N sub-Cholesky and without moving that factor to the host."""
+    O(N^2 P) solves against the N x N sub-Cholesky and without moving that factor to the host.
+
+    Not the reference's arithmetic: the factorisation adds the noise to the diagonal and it is subtracted again here, so
+    pend_K differs from pend_kappa - cross^T beta by O(eps (noise + amp2)) per entry (both forms cancel; neither is the
+    more accurate one).  The 1e-6 amp2 jitter of pend_kappa keeps pend_K that far from singular, ten orders above the
+    difference, so positive definiteness is decided the same way; the fantasies agree to 1e-9 of their scale on ordinary
+    problems and to 1e-6 with noise ~ amp2 and pending points 1e-5 apart
+    (tests/test_host_logic.py::test_fantasies_from_factor_rows_with_large_noise_and_nearly_duplicate_pending_points; through
+    the choosers, the reference's own pending goldens reproduce)."""
     mean, noise = hyper_row[0], hyper_row[1]
     n = vals.shape[0]
     p = l_rows.shape[0]

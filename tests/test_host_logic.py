@@ -676,3 +676,28 @@ def test_fantasies_from_the_bottom_rows_of_the_factor_equal_the_reference_form()
         f1, b1 = hostgp.fantasize_from_factor_rows(vals, row, chol[n:, :], gamma, z)
         scale = np.abs(f0).max()
         assert np.allclose(f1, f0, rtol=0, atol=1e-9 * scale) and np.allclose(b1, b0, rtol=0, atol=1e-9 * scale)
+
+
+def test_fantasies_from_factor_rows_with_large_noise_and_nearly_duplicate_pending_points():
+    """fantasize_from_factor_rows forms pend_K = L_S L_S^T - noise I (the noise is added by the factorisation
+    and taken off again), the reference pend_kappa - cross^T beta (GPEIChooser.py:229-236): equal in exact arithmetic,
+    different by O(eps (noise + amp2)) in floating point.  Where that matters most -- noise as large as the amplitude,
+    pending points 1e-5 apart (pend_K within the 1e-6 amp2 jitter of singular) -- both forms stay positive definite and
+    the fantasies agree to 1e-6 of their scale (the Cholesky factor of a matrix this close to singular amplifies the
+    1e-16 difference of its entries by up to 1 / sqrt(1e-6 jitter))."""
+    import scipy.linalg as spla
+    rs = np.random.RandomState(11)
+    for n, p, d, noise in ((60, 4, 3, 1.0), (200, 6, 5, 0.3), (90, 3, 2, 2.0)):
+        comp, pend = rs.rand(n, d), rs.rand(p, d)
+        pend[1] = pend[0] + 1e-5                 # nearly duplicate pending points
+        pend[2] = comp[7] + 1e-6                 # ... and one on top of an observation
+        vals = np.sin(3 * comp).sum(axis=1) + 0.01 * rs.randn(n)
+        row = np.concatenate(([vals.mean(), noise, 1.0], rs.uniform(0.5, 1.5, d)))
+        cp = np.concatenate((comp, pend))
+        chol = spla.cholesky(hostgp.obs_cov(row[2], row[1], row[3:], cp, "Matern52"), lower=True)
+        gamma = spla.solve_triangular(chol, np.concatenate((vals, np.zeros(p))) - row[0], lower=True)
+        z = rs.randn(p, 100)
+        f0, b0 = hostgp.fantasize_pending(comp, pend, vals, row, chol[:n, :n], z, "Matern52")      # raises if not PD
+        f1, b1 = hostgp.fantasize_from_factor_rows(vals, row, chol[n:, :], gamma, z)                # raises if not PD
+        scale = np.abs(f0).max()
+        assert np.allclose(f1, f0, rtol=0, atol=1e-6 * scale) and np.allclose(b1, b0, rtol=0, atol=1e-6 * scale)
