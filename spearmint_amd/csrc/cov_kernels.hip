@@ -93,19 +93,32 @@ void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad,
     }
 }
 
+// compute units of the current device (cached per device id: one process may drive several GPUs)
+static int spx_cov_cus()
+{
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 #include "cov_device.h"   // sqrt_pos / exp_neg / *_corr: shared with the log-likelihood path's in-kernel covariance (chol_kernels.hip)
 
+// The rows [jbeg, jend) x the 64 columns from c0 of draw h: the body of k_cov (one call per workgroup) and of k_cov_flat
+// (a workgroup's share of the launch, run by run).
 template <int MODE, int QC, int KIND>
-__global__ __launch_bounds__(256, 2) void k_cov(
+__device__ __forceinline__ void cov_run(
     const double* __restrict__ Xs, const double* __restrict__ s1,
     const double* __restrict__ Cs, const double* __restrict__ s2,
     const double* __restrict__ htab, const double* __restrict__ alpha,
-    double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int rows_per_wg)
+    double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int h, int c0, int jbeg, int jend)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.z;
-    const int c0 = blockIdx.x * 64;
     const int Q = Dp >> 2;
     const double* Xh = Xs + (size_t)h * Np * Dp;
     const double* Ch = Cs + (size_t)h * Mc * Dp;
@@ -177,8 +190,6 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     // MODE 0/1: a workgroup covers `rows_per_wg` rows (a multiple of 128) so that the prologue
     // (column-side fragment and norm loads, ~1-2 us of latency) is amortised over many row tiles
     // (MODE 3 relies on j0 being a multiple of 16 and c0 of 64: both hold for every launch geometry below)
-    const int jbeg = (MODE == 2) ? 0 : blockIdx.y * rows_per_wg;
-    const int jend = (MODE == 2) ? Np : min(Np, jbeg + rows_per_wg);
     for (int j0 = jbeg + wave * 16; j0 < jend; j0 += 64) {
         // tile-major output feeds the right-looking factorisation, which only ever reads the tiles on and below
         // the diagonal: the 64 x 64 tiles above it are not computed
@@ -226,6 +237,42 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     }
 }
 
+template <int MODE, int QC, int KIND>
+__global__ __launch_bounds__(256, 2) void k_cov(
+    const double* __restrict__ Xs, const double* __restrict__ s1,
+    const double* __restrict__ Cs, const double* __restrict__ s2,
+    const double* __restrict__ htab, const double* __restrict__ alpha,
+    double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int rows_per_wg)
+{
+    const int jbeg = (MODE == 2) ? 0 : blockIdx.y * rows_per_wg;
+    const int jend = (MODE == 2) ? Np : min(Np, jbeg + rows_per_wg);
+    cov_run<MODE, QC, KIND>(Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nchunks, ldo, blockIdx.z, blockIdx.x * 64, jbeg, jend);
+}
+
+// K(X*,X) of a LARGE launch (MODE 0), flat: the launch's work -- units of 128 rows x 64 columns, numbered draw-major, column
+// block next, row chunk fastest -- is dealt out in equal contiguous shares to a number of workgroups that is a whole multiple
+// of what the chip holds (2 per CU), so every residency round is full.  k_cov's grid at C3 was 1 792 workgroups on 512 places:
+// 3.5 rounds, the fourth half empty (13 % of the launch), 1 120 times per step.  Same arithmetic per element, same bits.
+template <int QC, int KIND>
+__global__ __launch_bounds__(256, 2) void k_cov_flat(
+    const double* __restrict__ Xs, const double* __restrict__ s1,
+    const double* __restrict__ Cs, const double* __restrict__ s2,
+    const double* __restrict__ htab, double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int nh)
+{
+    const int nrc = Np >> 7, ncb = Mc >> 6;
+    const int64_t per_h = (int64_t)ncb * nrc, U = per_h * nh;
+    int64_t u = U * blockIdx.x / gridDim.x;
+    const int64_t u1 = U * (blockIdx.x + 1) / gridDim.x;
+    while (u < u1) {
+        const int h = (int)(u / per_h);
+        const int rem = (int)(u - (int64_t)h * per_h);
+        const int cb = rem / nrc, rc = rem - cb * nrc;
+        const int run = (int)min((int64_t)(nrc - rc), u1 - u);       // row chunks of this column block that are ours
+        cov_run<0, QC, KIND>(Xs, s1, Cs, s2, htab, nullptr, out, N, Np, Mc, Dp, nchunks, ldo, h, cb * 64, rc * 128, (rc + run) * 128);
+        u += run;
+    }
+}
+
 template <int MODE, int KIND>
 static void launch_cov_kind(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                             const double* s2, const double* htab, const double* alpha, double* out,
@@ -237,6 +284,25 @@ static void launch_cov_kind(hipStream_t s, const double* Xs, const double* s1, c
     if (rpw && MODE == 3) rows_per_wg = atoi(rpw);
     dim3 grid(Mc / 64, (MODE == 2) ? 1 : (Np + rows_per_wg - 1) / rows_per_wg, nh);
     dim3 block(256);
+    if (MODE == 0) {
+        // a launch of several residency rounds: whole rounds, equal shares (k_cov_flat); `places` = 2 workgroups per CU
+        static const char* flat_env = getenv("SPX_COV_FLAT");   // dev: 0 = always the 3-D grid
+        const int64_t places = 2 * (int64_t)spx_cov_cus(), wgs = (int64_t)grid.x * grid.y * grid.z;
+        const int64_t units = (int64_t)nh * (Mc / 64) * (Np / 128);
+        if (wgs > places && units >= 4 * places && !(flat_env && *flat_env == '0')) {
+            // shares of at most 16 units (2048 rows x 64 columns): as many whole rounds as that takes
+            const int64_t rounds = (units + 16 * places - 1) / (16 * places);
+            const dim3 fgrid((unsigned)(places * rounds));
+#define SPX_COVF_LAUNCH(QC_)                                                                                   \
+    hipLaunchKernelGGL((k_cov_flat<QC_, KIND>), fgrid, block, 0, s, Xs, s1, Cs, s2, htab, out, N, Np, Mc, Dp, Q / QC_, ldo, nh)
+            if (Q == 1) SPX_COVF_LAUNCH(1);
+            else if (Q == 2) SPX_COVF_LAUNCH(2);
+            else if (Q == 4) SPX_COVF_LAUNCH(4);
+            else SPX_COVF_LAUNCH(8);
+#undef SPX_COVF_LAUNCH
+            return;
+        }
+    }
 #define SPX_COV_LAUNCH(QC_)                                                                        \
     hipLaunchKernelGGL((k_cov<MODE, QC_, KIND>), grid, block, 0, s, Xs, s1, Cs, s2, htab, alpha, out, N, \
                        Np, Mc, Dp, Q / QC_, ldo, rows_per_wg)

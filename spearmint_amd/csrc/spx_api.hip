@@ -341,7 +341,7 @@ static void note_flow_timeout(spx_handle* h)
 {
     h->flow_fallbacks += 1;
     h->flow_demoted = true;
-    h->flow_clean = 0;
+    h->flow_clean = -1;             // (the repeat of THIS call is not one of the clean factorisations that are counted)
     h->handoff_timeout = false;
 }
 // ... and the repeated call succeeded: SPX_OK, with a WARNING left in spx_last_error() (text starts with "warning:")

@@ -289,8 +289,11 @@ static int exchange_best(spx_multi* m)
         NCCLCHK(m, "ncclGroupStart", m->rccl.GroupStart());
         for (int i = 0; i < n; ++i) {
             spx_handle* k = m->kids[i];
-            NCCLCHK(m, "ncclAllGather", m->rccl.AllGather(k->rec_send.p, k->rec_recv.p, sizeof(SpxRecord), ncclChar, m->comms[i],
-                                         k->stream));
+            ncclResult_t r = m->rccl.AllGather(k->rec_send.p, k->rec_recv.p, sizeof(SpxRecord), ncclChar, m->comms[i], k->stream);
+            if (r != ncclSuccess) {
+                (void)m->rccl.GroupEnd();      // the group must not stay open on this thread: the next exchange would nest inside it
+                return fail(SPX_ERR_HIP, "ncclAllGather failed: %s", m->rccl.GetErrorString(r));
+            }
         }
         NCCLCHK(m, "ncclGroupEnd (the group of ncclAllGather / ncclAllReduce calls)", m->rccl.GroupEnd());
     } else {
@@ -357,8 +360,11 @@ static int exchange_sums(spx_multi* m)
         NCCLCHK(m, "ncclGroupStart", m->rccl.GroupStart());
         for (int i = 0; i < n; ++i) {
             spx_handle* k = m->kids[i];
-            NCCLCHK(m, "ncclAllReduce", m->rccl.AllReduce(k->ei_sum_full.p, k->ei_sum_full.p, (size_t)M, ncclFloat64, ncclSum, m->comms[i],
-                                         k->stream));
+            ncclResult_t r = m->rccl.AllReduce(k->ei_sum_full.p, k->ei_sum_full.p, (size_t)M, ncclFloat64, ncclSum, m->comms[i], k->stream);
+            if (r != ncclSuccess) {
+                (void)m->rccl.GroupEnd();      // (as above)
+                return fail(SPX_ERR_HIP, "ncclAllReduce failed: %s", m->rccl.GetErrorString(r));
+            }
         }
         NCCLCHK(m, "ncclGroupEnd (the group of ncclAllGather / ncclAllReduce calls)", m->rccl.GroupEnd());
     } else {
