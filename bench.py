@@ -491,6 +491,9 @@ def main():
     ap.add_argument("--hyper-shards", type=int, default=1,
                     help="N > 1 only: also time C4 in the optional 2-D partition of SURVEY 8(e) -- draws x candidates over "
                          "P_h x (N / P_h) ranks, one all-reduce(SUM) of the M-vector of EI sums (sub-record c4_2d)")
+    ap.add_argument("--lib-timeout", type=int, default=240,
+                    help="N > 1: seconds the variants whose collective runs inside libspx (c4_lib, c5_lib, c4_2d_lib) may take "
+                         "together before a watchdog prints the line without them")
     ap.add_argument("--c4-candidates", type=int, default=STRONG["c4"]["M"])
     ap.add_argument("--c5-candidates", type=int, default=STRONG["c5"]["M"])
     ap.add_argument("--event-steps", type=int, default=3, help="steps of the second (per-launch HIP event) pass")
@@ -819,103 +822,137 @@ def main():
             return err or "another rank could not attach the communicator"
         return None
 
-    if not args.skip_extras:
-        esteps = max(args.extra_steps, 5) if world > 1 else args.extra_steps
-        winners = {}
-        for name in ("c4", "c5"):
-            cfg = dict(STRONG[name])
-            cfg["M"] = int(getattr(args, "%s_candidates" % name))
-            sprob, scomp, svals, shyp = strong_problem(cfg)
-            lo, hi = spx_dist.shard_bounds(cfg["M"], world, rank)
-            rows = strong_rows(cfg, scomp, svals, lo, hi)
-            fl = FLAG_PER_SEC if cfg["per_sec"] else 0
-            variants = [(name, lib_collective)] if world == 1 else [(name, False), (name + "_lib", True)]
-            for key, use_lib in variants:
-                e2 = None
-                err = None
-                try:
-                    e2 = EngineCls(local_rank)
-                    e2.set_observations(scomp, svals)
-                    e2.set_candidates(rows, index_base=lo)
-                    e2.set_hypers(shyp)
-                    if cfg["per_sec"]:
-                        e2.set_time_model(sprob[4], sprob[5])
-                except Exception as ex:
-                    err = "%s: %s" % (type(ex).__name__, ex)
-                if not all_ok(err is None):
-                    err = err or "another rank failed to set the problem up"
-                elif use_lib:
-                    err = attach_lib(e2)
-                if err is None:
-                    run_steps(e2, fl, 1, lib=use_lib)
-                    sdt, sbest = run_steps(e2, fl, esteps, lib=use_lib, tag=key)
-                if e2 is not None:
-                    e2.close()
-                if rank == 0:
-                    if err is not None:
-                        out[key] = {"error": err, "n_gpus": world,
-                                    "collective": "libspx ncclAllGather (spx_comm_attach)" if use_lib else "torch.distributed"}
-                        continue
-                    sval = float(cfg["M"]) * cfg["H"] * esteps / sdt
-                    out[key] = {"value": sval, "unit": "EI evals/s", "scaling": "strong", "n_gpus": world,
-                                "steps": esteps, "warmup": 1, "ms_per_step": sdt / esteps * 1e3,
-                                "collective": "libspx ncclAllGather (spx_comm_attach)" if use_lib
-                                              else "torch.distributed all_gather_into_tensor",
-                                "rank_step_ms": rank_times.get(key), "ranks_seen": seen.get(key),
-                                "config": {"workload": cfg["desc"], "N_obs": cfg["N"], "candidates_total": cfg["M"],
-                                           "D": cfg["D"], "mcmc_iters": cfg["H"], "per_sec": cfg["per_sec"]},
-                                "best_index": sbest[0], "best_ei": sbest[1]}
-                    if key == name:
-                        out["%s_value" % name] = sval
-                    winners.setdefault(name, []).append((key, sbest[0], sbest[1]))
-        if rank == 0:
-            for name, ws in winners.items():
-                assert all(w[1:] == ws[0][1:] for w in ws), "collective variants disagree on the winner: %r" % (ws,)
+    # Order: every variant whose collective travels through torch.distributed first (c4, c5, c4_2d), THEN the ones whose
+    # collective runs inside libspx (c4_lib, c5_lib, c4_2d_lib) under a watchdog: that code has run with P > 1 only on the
+    # thread-rendezvous stand-in of the tests (no multi-GPU box was available to build on), and a collective that never
+    # returns must not cost the run its line -- after --lib-timeout seconds rank 0 prints what it has (the variant in
+    # flight marked as timed out) and every rank leaves.
+    winners = {}
 
-    # ---- optional: C4 in the 2-D (draws x candidates) partition, one all-reduce(SUM) of the EI-sum vector ----------
-    if args.hyper_shards > 1 and world > 1 and not args.skip_extras:
-        esteps = max(args.extra_steps, 5)
+    def strong_variant(name, key, use_lib, esteps):
+        cfg = dict(STRONG[name])
+        cfg["M"] = int(getattr(args, "%s_candidates" % name))
+        sprob, scomp, svals, shyp = strong_problem(cfg)
+        lo, hi = spx_dist.shard_bounds(cfg["M"], world, rank)
+        rows = strong_rows(cfg, scomp, svals, lo, hi)
+        fl = FLAG_PER_SEC if cfg["per_sec"] else 0
+        e2 = None
+        err = None
+        try:
+            e2 = EngineCls(local_rank)
+            e2.set_observations(scomp, svals)
+            e2.set_candidates(rows, index_base=lo)
+            e2.set_hypers(shyp)
+            if cfg["per_sec"]:
+                e2.set_time_model(sprob[4], sprob[5])
+        except Exception as ex:
+            err = "%s: %s" % (type(ex).__name__, ex)
+        if not all_ok(err is None):
+            err = err or "another rank failed to set the problem up"
+        elif use_lib:
+            err = attach_lib(e2)
+        if err is None:
+            run_steps(e2, fl, 1, lib=use_lib)
+            sdt, sbest = run_steps(e2, fl, esteps, lib=use_lib, tag=key)
+        if e2 is not None:
+            e2.close()
+        if rank != 0:
+            return
+        if err is not None:
+            out[key] = {"error": err, "n_gpus": world,
+                        "collective": "libspx ncclAllGather (spx_comm_attach)" if use_lib else "torch.distributed"}
+            return
+        sval = float(cfg["M"]) * cfg["H"] * esteps / sdt
+        out[key] = {"value": sval, "unit": "EI evals/s", "scaling": "strong", "n_gpus": world,
+                    "steps": esteps, "warmup": 1, "ms_per_step": sdt / esteps * 1e3,
+                    "collective": "libspx ncclAllGather (spx_comm_attach)" if use_lib
+                                  else "torch.distributed all_gather_into_tensor",
+                    "rank_step_ms": rank_times.get(key), "ranks_seen": seen.get(key),
+                    "config": {"workload": cfg["desc"], "N_obs": cfg["N"], "candidates_total": cfg["M"],
+                               "D": cfg["D"], "mcmc_iters": cfg["H"], "per_sec": cfg["per_sec"]},
+                    "best_index": sbest[0], "best_ei": sbest[1]}
+        if key == name:
+            out["%s_value" % name] = sval
+        winners.setdefault(name, []).append((key, sbest[0], sbest[1]))
+
+    # C4 in the optional 2-D (draws x candidates) partition, one all-reduce(SUM) of the EI-sum vector
+    def partition_variant(key, use_lib, esteps):
         cfg = dict(STRONG["c4"])
         cfg["M"] = int(args.c4_candidates)
         sprob, scomp, svals, shyp = strong_problem(cfg)
         (lo, hi), (h0, h1) = spx_dist.shard_2d(cfg["M"], cfg["H"], world, rank, args.hyper_shards)
         rows = strong_rows(cfg, scomp, svals, lo, hi)
         part = "%d draw shards x %d candidate shards" % spx_dist.grid_2d(world, args.hyper_shards)
-        for key, use_lib in (("c4_2d", False), ("c4_2d_lib", True)):
-            e3 = EngineCls(local_rank)
-            e3.set_observations(scomp, svals)
-            e3.set_candidates(rows, index_base=lo)
-            e3.set_hypers(shyp[h0:h1])
-            err = None
-            if use_lib:
-                err = attach_lib(e3)
-                if err is None:
-                    e3.set_partition(args.hyper_shards, cfg["M"], cfg["H"])
-
-            def step_2d():
-                e3.ei_step(0)
-                if use_lib:                                       # ncclAllReduce + argmax ran inside spx_ei_run
-                    return e3.best()
-                sums = np.sum(e3.ei_draws(), axis=1)              # this rank's draws, its candidates: D2H of M_local x H_local
-                return spx_dist.allreduce_ei_sums(sums, lo, cfg["M"], cfg["H"], device=tdev)[:2]
+        e3 = EngineCls(local_rank)
+        e3.set_observations(scomp, svals)
+        e3.set_candidates(rows, index_base=lo)
+        e3.set_hypers(shyp[h0:h1])
+        err = None
+        if use_lib:
+            err = attach_lib(e3)
             if err is None:
-                step_2d()
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(esteps):
-                    r2 = step_2d()
-                sync()
-                dt2 = max_over_ranks(time.perf_counter() - t0)
-            e3.close()
-            if rank == 0:
-                if err is not None:
-                    out[key] = {"error": err, "n_gpus": world, "partition": part}
-                    continue
-                out[key] = {"value": float(cfg["M"]) * cfg["H"] * esteps / dt2, "unit": "EI evals/s",
-                            "scaling": "strong", "n_gpus": world, "partition": part, "steps": esteps,
-                            "collective": ("libspx ncclAllReduce(SUM) of %d doubles on the handle's stream (spx_set_partition)"
-                                           if use_lib else "host-side sums + torch all-reduce(SUM) of %d doubles") % cfg["M"],
-                            "ms_per_step": dt2 / esteps * 1e3, "best_index": int(r2[0]), "best_ei": float(r2[1])}
+                e3.set_partition(args.hyper_shards, cfg["M"], cfg["H"])
+
+        def step_2d():
+            e3.ei_step(0)
+            if use_lib:                                       # ncclAllReduce + argmax ran inside spx_ei_run
+                return e3.best()
+            sums = np.sum(e3.ei_draws(), axis=1)              # this rank's draws, its candidates: D2H of M_local x H_local
+            return spx_dist.allreduce_ei_sums(sums, lo, cfg["M"], cfg["H"], device=tdev)[:2]
+        if err is None:
+            step_2d()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(esteps):
+                r2 = step_2d()
+            sync()
+            dt2 = max_over_ranks(time.perf_counter() - t0)
+        e3.close()
+        if rank != 0:
+            return
+        if err is not None:
+            out[key] = {"error": err, "n_gpus": world, "partition": part}
+            return
+        out[key] = {"value": float(cfg["M"]) * cfg["H"] * esteps / dt2, "unit": "EI evals/s",
+                    "scaling": "strong", "n_gpus": world, "partition": part, "steps": esteps,
+                    "collective": ("libspx ncclAllReduce(SUM) of %d doubles on the handle's stream (spx_set_partition)"
+                                   if use_lib else "host-side sums + torch all-reduce(SUM) of %d doubles") % cfg["M"],
+                    "ms_per_step": dt2 / esteps * 1e3, "best_index": int(r2[0]), "best_ei": float(r2[1])}
+
+    if not args.skip_extras:
+        esteps = max(args.extra_steps, 5) if world > 1 else args.extra_steps
+        two_d = args.hyper_shards > 1 and world > 1
+        for name in ("c4", "c5"):
+            strong_variant(name, name, lib_collective if world == 1 else False, esteps)
+        if two_d:
+            partition_variant("c4_2d", False, esteps)
+        if world > 1:
+            import threading
+            in_flight = {"key": None}
+
+            def expired():
+                if rank == 0:
+                    out["lib_collective_watchdog"] = ("the library-collective variants did not finish within %d s (in flight: %s); "
+                                                      "this line was printed by the watchdog" % (args.lib_timeout, in_flight["key"]))
+                    if in_flight["key"] and in_flight["key"] not in out:
+                        out[in_flight["key"]] = {"error": "timed out after %d s (watchdog)" % args.lib_timeout, "n_gpus": world}
+                    print(json.dumps(out))
+                    sys.stdout.flush()
+                os._exit(0)
+
+            dog = threading.Timer(float(args.lib_timeout), expired)
+            dog.daemon = True
+            dog.start()
+            for name in ("c4", "c5"):
+                in_flight["key"] = name + "_lib"
+                strong_variant(name, name + "_lib", True, esteps)
+            if two_d:
+                in_flight["key"] = "c4_2d_lib"
+                partition_variant("c4_2d_lib", True, esteps)
+            dog.cancel()
+        if rank == 0:
+            for name, ws in winners.items():
+                assert all(w[1:] == ws[0][1:] for w in ws), "collective variants disagree on the winner: %r" % (ws,)
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

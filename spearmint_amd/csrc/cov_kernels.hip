@@ -156,7 +156,12 @@ __device__ __forceinline__ void cov_run(
             double gv[4], cv[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) gv[nt] = acc[nt][r];
+#if defined(SPX_COV_ABL) && SPX_COV_ABL == 2   // dev, timing only (WRONG results): no correlation function
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = (gv[nt] - s1v) - s2v[nt];
+#else
             corr_of_kind<KIND, 4>(gv, s1v, s2v, cv);
+#endif
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int c = c0 + 16 * nt + li;
@@ -164,6 +169,9 @@ __device__ __forceinline__ void cov_run(
                 if (MODE == 0) {
                     // pad rows (j >= N) are written as 0 (amp_j = 0); a NaN column stays NaN there,
                     // which is harmless: that candidate's result is NaN anyway
+#if defined(SPX_COV_ABL) && SPX_COV_ABL == 1   // dev, timing only (WRONG results): no store stream (a value that never occurs)
+                    if (corr == 123.456)
+#endif
                     out[((size_t)h * Np + j) * ldo + c] = amp_j * corr;
                 } else if (MODE == 1 || MODE == 3) {
 #pragma clang fp contract(off)
@@ -210,10 +218,17 @@ __device__ __forceinline__ void cov_run(
                     for (int q = 0; q < QC; ++q) bf[nt][q] = p[q];
                 }
             }
+#if defined(SPX_COV_ABL) && SPX_COV_ABL == 3   // dev, timing only (WRONG results): no Gram MFMAs
+#pragma unroll
+            for (int q = 0; q < QC; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt][q & 3] += af[q] * bf[nt][q];
+#else
 #pragma unroll
             for (int q = 0; q < QC; ++q)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[nt] = MFMA_F64(af[q], bf[nt][q], acc[nt]);
+#endif
         }
         epilogue(acc, j0);
     }
