@@ -53,7 +53,7 @@ void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const do
                      int kind = SPX_COV_MATERN52);
 void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                       const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
-                      int Dp, int nh, int kind = SPX_COV_MATERN52);
+                      int Dp, int nh, int kind = SPX_COV_MATERN52, int live_rows = 0 /*> 0: rows from here on are NOT written*/);
 void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                        const double* s2, const double* htab, const double* alpha, double* out,
                        int N, int Np, int Mc, int Dp, int nh, int kind = SPX_COV_MATERN52);
@@ -112,8 +112,9 @@ void launch_sobol_grid(hipStream_t s, const uint32_t* dirs, int dim, int64_t n, 
 // predict_kernels.hip
 void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const double* Kst, const double* gamma,
                          double* part_ss, double* part_bg, int Np, int Mc, int nh, int part_nh, int part_h0,
-                         const double* gammaS = nullptr, int S = 0, double* part_bgS = nullptr);
+                         const double* gammaS = nullptr, int S = 0, double* part_bgS = nullptr, int nlive = 0);
 bool predict_gemm_variant_ok(int v);
+int predict_gemm_padding_plan(int variant, int N, int Np);
 void launch_ei_finalize_fant(hipStream_t s, const double* part_ss, const double* part_bgS,
                              const double* htab, const double* bests, const double* time_m,
                              double* ei_draw, int nrb, int Mc, int nh, int S, int64_t c0, int64_t M,

@@ -257,10 +257,13 @@ __global__ __launch_bounds__(256, 2) void k_cov(
     const double* __restrict__ Xs, const double* __restrict__ s1,
     const double* __restrict__ Cs, const double* __restrict__ s2,
     const double* __restrict__ htab, const double* __restrict__ alpha,
-    double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int rows_per_wg)
+    double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int rows_per_wg, int live_rows)
 {
+    // live_rows (MODE 0, a multiple of 16, >= N): the rows from there on are padding whose consumer skips them
+    // (k_predict_gemm_tri<true>): they are not computed and not written
+    const int jtop = (MODE == 0 && live_rows > 0) ? live_rows : Np;
     const int jbeg = (MODE == 2) ? 0 : blockIdx.y * rows_per_wg;
-    const int jend = (MODE == 2) ? Np : min(Np, jbeg + rows_per_wg);
+    const int jend = (MODE == 2) ? Np : min(jtop, jbeg + rows_per_wg);
     cov_run<MODE, QC, KIND>(Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nchunks, ldo, blockIdx.z, blockIdx.x * 64, jbeg, jend);
 }
 
@@ -272,9 +275,11 @@ template <int QC, int KIND>
 __global__ __launch_bounds__(256, 2) void k_cov_flat(
     const double* __restrict__ Xs, const double* __restrict__ s1,
     const double* __restrict__ Cs, const double* __restrict__ s2,
-    const double* __restrict__ htab, double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int nh)
+    const double* __restrict__ htab, double* __restrict__ out, int N, int Np, int Mc, int Dp, int nchunks, int64_t ldo, int nh,
+    int live_rows)
 {
-    const int nrc = Np >> 7, ncb = Mc >> 6;
+    const int jtop = live_rows > 0 ? live_rows : Np;        // (as in k_cov)
+    const int nrc = (jtop + 127) >> 7, ncb = Mc >> 6;       // row chunks that hold live rows
     const int64_t per_h = (int64_t)ncb * nrc, U = per_h * nh;
     int64_t u = U * blockIdx.x / gridDim.x;
     const int64_t u1 = U * (blockIdx.x + 1) / gridDim.x;
@@ -283,7 +288,8 @@ __global__ __launch_bounds__(256, 2) void k_cov_flat(
         const int rem = (int)(u - (int64_t)h * per_h);
         const int cb = rem / nrc, rc = rem - cb * nrc;
         const int run = (int)min((int64_t)(nrc - rc), u1 - u);       // row chunks of this column block that are ours
-        cov_run<0, QC, KIND>(Xs, s1, Cs, s2, htab, nullptr, out, N, Np, Mc, Dp, nchunks, ldo, h, cb * 64, rc * 128, (rc + run) * 128);
+        cov_run<0, QC, KIND>(Xs, s1, Cs, s2, htab, nullptr, out, N, Np, Mc, Dp, nchunks, ldo, h, cb * 64, rc * 128,
+                             min(jtop, (rc + run) * 128));
         u += run;
     }
 }
@@ -291,25 +297,26 @@ __global__ __launch_bounds__(256, 2) void k_cov_flat(
 template <int MODE, int KIND>
 static void launch_cov_kind(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                             const double* s2, const double* htab, const double* alpha, double* out,
-                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo)
+                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo, int live_rows)
 {
     const int Q = Dp / 4;
     int rows_per_wg = (Np >= 1024) ? 512 : ((Np >= 256) ? 256 : 128);
     static const char* rpw = getenv("SPX_COV_RPW");   // dev
     if (rpw && MODE == 3) rows_per_wg = atoi(rpw);
-    dim3 grid(Mc / 64, (MODE == 2) ? 1 : (Np + rows_per_wg - 1) / rows_per_wg, nh);
+    const int row_top = (MODE == 0 && live_rows > 0) ? live_rows : Np;     // (MODE 0: rows past live_rows are left alone)
+    dim3 grid(Mc / 64, (MODE == 2) ? 1 : (row_top + rows_per_wg - 1) / rows_per_wg, nh);
     dim3 block(256);
     if (MODE == 0) {
         // a launch of several residency rounds: whole rounds, equal shares (k_cov_flat); `places` = 2 workgroups per CU
         static const char* flat_env = getenv("SPX_COV_FLAT");   // dev: 0 = always the 3-D grid
         const int64_t places = 2 * (int64_t)spx_cov_cus(), wgs = (int64_t)grid.x * grid.y * grid.z;
-        const int64_t units = (int64_t)nh * (Mc / 64) * (Np / 128);
+        const int64_t units = (int64_t)nh * (Mc / 64) * (((live_rows > 0 ? live_rows : Np) + 127) / 128);
         if (wgs > places && units >= 4 * places && !(flat_env && *flat_env == '0')) {
             // shares of at most 16 units (2048 rows x 64 columns): as many whole rounds as that takes
             const int64_t rounds = (units + 16 * places - 1) / (16 * places);
             const dim3 fgrid((unsigned)(places * rounds));
 #define SPX_COVF_LAUNCH(QC_)                                                                                   \
-    hipLaunchKernelGGL((k_cov_flat<QC_, KIND>), fgrid, block, 0, s, Xs, s1, Cs, s2, htab, out, N, Np, Mc, Dp, Q / QC_, ldo, nh)
+    hipLaunchKernelGGL((k_cov_flat<QC_, KIND>), fgrid, block, 0, s, Xs, s1, Cs, s2, htab, out, N, Np, Mc, Dp, Q / QC_, ldo, nh, live_rows)
             if (Q == 1) SPX_COVF_LAUNCH(1);
             else if (Q == 2) SPX_COVF_LAUNCH(2);
             else if (Q == 4) SPX_COVF_LAUNCH(4);
@@ -320,7 +327,7 @@ static void launch_cov_kind(hipStream_t s, const double* Xs, const double* s1, c
     }
 #define SPX_COV_LAUNCH(QC_)                                                                        \
     hipLaunchKernelGGL((k_cov<MODE, QC_, KIND>), grid, block, 0, s, Xs, s1, Cs, s2, htab, alpha, out, N, \
-                       Np, Mc, Dp, Q / QC_, ldo, rows_per_wg)
+                       Np, Mc, Dp, Q / QC_, ldo, rows_per_wg, live_rows)
     if (Q == 1) SPX_COV_LAUNCH(1);
     else if (Q == 2) SPX_COV_LAUNCH(2);
     else if (Q == 4) SPX_COV_LAUNCH(4);
@@ -331,21 +338,21 @@ static void launch_cov_kind(hipStream_t s, const double* Xs, const double* s1, c
 template <int MODE>
 static void launch_cov_mode(hipStream_t s, int kind, const double* Xs, const double* s1, const double* Cs,
                             const double* s2, const double* htab, const double* alpha, double* out,
-                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo)
+                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo, int live_rows = 0)
 {
     if (kind == SPX_COV_MATERN32)
-        launch_cov_kind<MODE, SPX_COV_MATERN32>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo);
+        launch_cov_kind<MODE, SPX_COV_MATERN32>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows);
     else if (kind == SPX_COV_ARDSE)
-        launch_cov_kind<MODE, SPX_COV_ARDSE>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo);
+        launch_cov_kind<MODE, SPX_COV_ARDSE>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows);
     else
-        launch_cov_kind<MODE, SPX_COV_MATERN52>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo);
+        launch_cov_kind<MODE, SPX_COV_MATERN52>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows);
 }
 
 void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                       const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
-                      int Dp, int nh, int kind)
+                      int Dp, int nh, int kind, int live_rows)
 {
-    launch_cov_mode<0>(s, kind, Xs, s1, Cs, s2, htab, nullptr, Kst, N, Np, Mc, Dp, nh, Mc);
+    launch_cov_mode<0>(s, kind, Xs, s1, Cs, s2, htab, nullptr, Kst, N, Np, Mc, Dp, nh, Mc, live_rows);
 }
 
 // X2s = 2 * Xs (the reference multiplies the second operand by 2, gp.py:50)

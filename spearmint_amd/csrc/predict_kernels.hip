@@ -481,6 +481,174 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm_tri(
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_predict_gemm_tail (round 5): the LAST row block of a problem whose observation count is not a multiple of 128.
+// N is padded to the GEMM's 128-row tiles with an identity: pad rows of K* are zero, pad rows of W are unit vectors.  Of the
+// last row block only the first lt = ceil(N / 16) - 8 ib 16-row tiles hold observations, and of its K steps only the first
+// nlive = ceil(N / 16) multiply anything but zeros.  k_predict_gemm_tri computes all of it (N = 129: 16 K steps x 8 row tiles
+// for ONE live row; averaged over N, a third of a mid-sized problem's GEMM is padding).  This kernel is k_predict_gemm_tri for
+// that block with both bounds applied -- same tile, same wave rows owning the 16-row tiles alternately, same LDS-DMA pipeline,
+// the K steps in the same order, the zero tiles of the diagonal steps skipped the same way -- so every live accumulator holds
+// the bits of the padded computation, the dead ones are the exact zeros they would have been, and the epilogue's sums (dead
+// tiles left out of the fma chains: fma(0, g, s) = s) are the same numbers.  The launcher gives row blocks 0 .. nrb - 2 to
+// k_predict_gemm_tri as before; K(X*,X) leaves the rows from 16 nlive on unwritten.  ML = ceil(lt / 2) <= 3: the
+// accumulator tiles per wave (lt = 7 is left to the padded path: one tile of sixteen is not worth a kernel).
+template <int ML>
+__global__ __launch_bounds__(256, 2) void k_predict_gemm_tail(
+    const double* __restrict__ WT, const double* __restrict__ Kst,
+    const double* __restrict__ gamma, double* __restrict__ part_ss,
+    double* __restrict__ part_bg, int Np, int Mc, int nh, int ncb, int ib, int nlive,
+    int part_nh, int part_h0, const double* __restrict__ gammaS, int S, double* __restrict__ part_bgS)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                      // [2][BK][LDT]
+    double* Bs = smem + 2 * BK * LDT;       // [2][BK][LDT]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int NW = 4, NQ = 4;
+
+    const int ncbx = (ncb + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int h = slot / ncbx;
+    const int cb = (slot % ncbx) * 8 + xcd;
+    if (cb >= ncb) return;
+
+    const int lt = nlive - 8 * ib;                 // live 16-row tiles of this block: 1 .. 2 ML
+    const int mlive = (lt - wm + 1) >> 1;          // ... of this wave row (tiles 2 mt + wm < lt); wave row 1 may have none
+    const double* Ag = WT + (size_t)h * Np * Np + (size_t)ib * BM;
+    const double* Bg = Kst + (size_t)h * Np * Mc + (size_t)cb * BN;
+    const int nk = nlive;                          // (<= 8 (ib + 1): the K steps of live rows of K*)
+    const int nfull = 8 * ib;                      // from here on: the diagonal block
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    const unsigned loff = (unsigned)lane * 16u;
+    d4 acc[ML][4];
+#pragma unroll
+    for (int mt = 0; mt < ML; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+#define SPX_DMA_ROW(GPTR_, LPTR_)                                                                          \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                          \
+                 :: "v"(loff), "s"(GPTR_), "s"((unsigned)(size_t)(lds_void_t*)(LPTR_)) : "memory")
+#define SPX_DMA_TILE(KT_, BUF_)                                                                            \
+    {                                                                                                      \
+        const size_t j0_ = (size_t)(KT_) * BK;                                                             \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
+            const int row = wave + NW * q;                                                                 \
+            SPX_DMA_ROW(Ag + (j0_ + row) * Np, As + (BUF_) * BK * LDT + row * LDT);                        \
+            SPX_DMA_ROW(Bg + (j0_ + row) * Mc, Bs + (BUF_) * BK * LDT + row * LDT);                        \
+        }                                                                                                  \
+    }
+    SPX_DMA_TILE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int j = 0; j < nk; ++j) {
+        // diagonal step d = j - nfull: the tiles 2 mt + wm < d of W are zero (as in k_predict_gemm_tri)
+        const int m0 = (j >= nfull) ? ((j - nfull - wm + 1) >> 1) : 0;
+        if (j + 1 < nk) SPX_DMA_TILE(j + 1, cur ^ 1)
+        const double* Ac = As + cur * BK * LDT + 16 * wm + li;
+        const double* Bc = Bs + cur * BK * LDT + 64 * wn + li;
+        if (m0 < mlive) {
+#pragma unroll
+            for (int k0 = 0; k0 < BK; k0 += 4) {
+                double b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = Bc[(k0 + g) * LDT + 16 * t];
+#pragma unroll
+                for (int mt = 0; mt < ML; ++mt)
+                    if (mt >= m0 && mt < mlive) {
+                        const double a = Ac[(k0 + g) * LDT + 32 * mt];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA_F64(a, b[nt], acc[mt][nt]);
+                    }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef SPX_DMA_TILE
+#undef SPX_DMA_ROW
+
+    // ---- epilogue: k_predict_gemm_tri's sums with the dead tiles (exact zeros there) left out of the chains ----
+    const double* gh = gamma + (size_t)h * Np + (size_t)ib * BM + 16 * wm;
+    double gam[ML][4];
+#pragma unroll
+    for (int mt = 0; mt < ML; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gam[mt][r] = (mt < mlive) ? gh[32 * mt + g + 4 * r] : 0.0;
+    double* red = smem;  // [2 (wm)][128][2]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        double ss = 0.0, bg = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < ML; ++mt)
+            if (mt < mlive) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = acc[mt][nt][r];
+                    ss = fma(v, v, ss);
+                    bg = fma(v, gam[mt][r], bg);
+                }
+            }
+        ss += __shfl_xor(ss, 16);
+        bg += __shfl_xor(bg, 16);
+        ss += __shfl_xor(ss, 32);
+        bg += __shfl_xor(bg, 32);
+        if (g == 0) {
+            const int c = 64 * wn + 16 * nt + li;
+            red[(wm * BN + c) * 2 + 0] = ss;
+            red[(wm * BN + c) * 2 + 1] = bg;
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        const size_t o = ((size_t)ib * part_nh + part_h0 + h) * Mc + (size_t)cb * BN + tid;
+        part_ss[o] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+        part_bg[o] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+    }
+    if (S > 0) {   // pending-experiment fantasies: one partial per wave row, summed by k_ei_finalize_fant
+        const double* gS = gammaS + (size_t)h * S * Np + (size_t)ib * BM + 16 * wm;
+        double* outS = part_bgS + ((((size_t)ib * 2 + wm) * nh + h) * S) * Mc + (size_t)cb * BN + 64 * wn;
+        for (int sidx = 0; sidx < S; ++sidx) {
+            const double* gs = gS + (size_t)sidx * Np;
+            double gv[ML][4];
+#pragma unroll
+            for (int mt = 0; mt < ML; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[mt][r] = (mt < mlive) ? gs[32 * mt + g + 4 * r] : 0.0;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                double bg = 0.0;
+#pragma unroll
+                for (int mt = 0; mt < ML; ++mt)
+                    if (mt < mlive) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bg = fma(acc[mt][nt][r], gv[mt][r], bg);
+                    }
+                bg += __shfl_xor(bg, 16);
+                bg += __shfl_xor(bg, 32);
+                if (g == 0) outS[(size_t)sidx * Mc + 16 * nt + li] = bg;
+            }
+        }
+    }
+}
+
+// what the production GEMM does with a padded observation count: 0 = nothing to skip (or not this variant), else
+// nlive = ceil(N / 16): the last row block goes to k_predict_gemm_tail, K(X*,X) stops at row 16 nlive
+int predict_gemm_padding_plan(int variant, int N, int Np)
+{
+    if (!(variant == 0 || variant == 32)) return 0;
+    const int nlive = (N + 15) / 16;
+    const int lt = nlive - 8 * (Np / BM - 1);      // live 16-row tiles of the last row block
+    return (lt >= 1 && lt <= 6) ? nlive : 0;
+}
+
 // Variants (spx_set_option "gemm_waves", per handle): 0 / 32 = production (k_predict_gemm_tri: 4 waves, LDS-DMA
 // staging, zero tiles of the diagonal block skipped -- measured fastest), 14 = the same without the skipping
 // (k_predict_gemm; production until round 2), 4 / 8 = 4 / 8 waves with register staging, 18 = 8 waves with LDS-DMA, 24 = LDS-DMA
@@ -511,9 +679,10 @@ static void launch_gemm_variant(hipStream_t s, int grid, size_t lds, const doubl
                        part_bg, Np, Mc, nh, ncb, nrb, part_nh, part_h0, gammaS, S, part_bgS);
 }
 
+// nlive: predict_gemm_padding_plan()'s figure when the caller wants the padding of N skipped (and has told K(X*,X) so), else 0
 void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const double* Kst, const double* gamma,
                          double* part_ss, double* part_bg, int Np, int Mc, int nh, int part_nh, int part_h0,
-                         const double* gammaS, int S, double* part_bgS)
+                         const double* gammaS, int S, double* part_bgS, int nlive)
 {
     const int ncb = Mc / BN, nrb = Np / BM;
     const size_t lds = (size_t)(4 * BK * LDT) * sizeof(double);
@@ -525,9 +694,28 @@ void launch_predict_gemm(hipStream_t s, int variant, const double* WT, const dou
     // form only (14 = the round-1 production kernel: 4 waves, LDS-DMA staging).
     const int v = (S > 0 && variant != 0 && variant != 32) ? 14 : variant;
     if (v == 0 || v == 32) {
-        SPX_LDS_ATTR(k_predict_gemm_tri, lds);
-        hipLaunchKernelGGL(k_predict_gemm_tri, dim3(grid), dim3(256), lds, s, WT, Kst, gamma, part_ss, part_bg, Np, Mc,
-                           nh, ncb, nrb, part_nh, part_h0, gammaS, S, part_bgS);
+        const bool tail = nlive > 0 && predict_gemm_padding_plan(v, 16 * nlive, Np) == nlive;   // (the caller planned with it)
+        const int nrb_main = tail ? nrb - 1 : nrb;
+        if (tail) {   // the short block first: it is the one that would otherwise start last and run alone
+            const int lt = nlive - 8 * (nrb - 1), ml = (lt + 1) / 2;
+            const int tgrid = 8 * ((ncb + 7) / 8) * nh;
+#define SPX_TAIL(ML_)                                                                                                   \
+    do {                                                                                                                \
+        SPX_LDS_ATTR(k_predict_gemm_tail<ML_>, lds);                                                                    \
+        hipLaunchKernelGGL(k_predict_gemm_tail<ML_>, dim3(tgrid), dim3(256), lds, s, WT, Kst, gamma, part_ss, part_bg, Np, Mc, \
+                           nh, ncb, nrb - 1, nlive, part_nh, part_h0, gammaS, S, part_bgS);                              \
+    } while (0)
+            if (ml == 1) SPX_TAIL(1);
+            else if (ml == 2) SPX_TAIL(2);
+            else SPX_TAIL(3);
+#undef SPX_TAIL
+        }
+        if (nrb_main > 0) {
+            const int mgrid = 8 * ((ncb + 7) / 8) * nrb_main * nh;
+            SPX_LDS_ATTR(k_predict_gemm_tri, lds);
+            hipLaunchKernelGGL(k_predict_gemm_tri, dim3(mgrid), dim3(256), lds, s, WT, Kst, gamma, part_ss, part_bg, Np, Mc,
+                               nh, ncb, nrb_main, part_nh, part_h0, gammaS, S, part_bgS);
+        }
         return;
     }
     switch (v) {

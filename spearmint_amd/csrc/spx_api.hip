@@ -242,6 +242,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_ps = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
+    if (!strcmp(name, "gemm_partial")) {   // N not a multiple of 128: skip the padding's K steps / row tiles / K* rows (1, default) or compute them (0)
+        h->gemm_partial = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
     if (!strcmp(name, "streams")) {  // 1 = everything on one stream (default), 2 = alternate EI work items
         h->nstreams = value == 2 ? 2 : 1;
         return SPX_OK;
@@ -804,6 +808,12 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     h->ev_used = 0;
     hipEvent_t t0 = h->ev_t0, t1 = h->ev_t1;
     HIPCHK(hipEventRecord(t0, s));
+    // N is padded to the predict GEMM's 128-row tiles with an identity: the production GEMM skips what the padding would
+    // multiply (K steps and row tiles from tile ceil(N / 16) on) and K(X*,X) then leaves those rows unwritten.  Same bits.
+    const int gemm_nlive = (!fused && h->gemm_partial != 0) ? predict_gemm_padding_plan(h->gemm_variant, (int)N, Np) : 0;
+    const bool skip_pad = gemm_nlive > 0;
+    const int cov_live_rows = 16 * gemm_nlive;
+    h->last_skip_pad = skip_pad;
 
     const double* ls = h->hyp.d() + 3;
     const size_t nn = (size_t)Np * Np;
@@ -871,7 +881,8 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
             hipStream_t Pi = (item == 0) ? Pc : P;
             TIMED_S(ST_COV_CROSS, Pi, launch_cov_cross(Pi, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
                                                       Cs + (size_t)h0 * mc * Dp, s2 + (size_t)h0 * mc,
-                                                      h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb, dev_kind(h)));
+                                                      h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb, dev_kind(h),
+                                                      cov_live_rows));
             if (ns == 2) {
                 HIPCHK(hipEventRecord(h->ev_sync[k], P));
                 HIPCHK(hipStreamWaitEvent(G, h->ev_sync[k], 0));
@@ -884,7 +895,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
                                                             h->gamma.d() + (size_t)h0 * Np, h->part_ss[0].d(),
                                                             h->part_bg[0].d(), Np, mc, nhb, S > 0 ? nhb : H, S > 0 ? 0 : h0,
                                                             S > 0 ? h->gammaS.d() + (size_t)h0 * S * Np : nullptr, S,
-                                                            S > 0 ? h->part_bgS[k].d() : nullptr));
+                                                            S > 0 ? h->part_bgS[k].d() : nullptr, gemm_nlive));
             if (S > 0)
                 TIMED_S(ST_EI_FINALIZE, G, launch_ei_finalize_fant(G, h->part_ss[0].d(), h->part_bgS[k].d(),
                                                                    h->htab.d() + (size_t)h0 * SPX_HT,
@@ -1333,6 +1344,7 @@ int spx_get_stat(spx_handle* h, const char* name, int64_t* value)
     else if (!strcmp(name, "ranks_seen")) *value = h->comm ? h->ranks_seen : 1;   // records in the table of the last all-gather (the ranks that took part)
     else if (!strcmp(name, "n_cu")) *value = h->n_cu;
     else if (!strcmp(name, "last_step_fused")) *value = h->last_fused ? 1 : 0; // the last EI pass ran k_ei_fused128
+    else if (!strcmp(name, "last_step_skipped_padding")) *value = h->last_skip_pad ? 1 : 0;   // ... skipped the padding of N (k_predict_gemm_tri<true>)
     else return fail(SPX_ERR_ARG, "spx_get_stat: unknown statistic '%s'", name);
     return SPX_OK;
 }

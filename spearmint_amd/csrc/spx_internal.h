@@ -113,6 +113,8 @@ struct spx_handle {
     int cov_kind = 0;                   // SPX_COVAR_* (option "covar"); SE = ARDSE kernels on unit length scales
     int lean_lazy = -1;                 // option "lean_lazy": 0 / 1 / -1 = by batch size
     int gemm_variant = 0;               // predict-GEMM variant of THIS handle (option "gemm_waves"); 0 = production
+    int gemm_partial = -1;              // option "gemm_partial": skip the padding of N in the EI pass 1 / 0 / -1 = default (on)
+    bool last_skip_pad = false;         // the last EI pass did
     struct spx_multi* multi = nullptr;  // non-null: this handle fronts several per-GPU handles (spx_multi.hip)
     struct spx_comm* comm = nullptr;    // non-null: one-process-per-GPU communicator attached (spx_comm_attach)
 

@@ -637,6 +637,62 @@ def test_flat_covariance_launch_is_bit_identical(eng, tmp_path):
     assert_ei_close(a[3][:3000], ref)
 
 
+@pytest.mark.parametrize("N,D,H,expect_skip", [(129, 3, 4, True), (150, 8, 3, True), (200, 5, 2, True), (230, 4, 2, False),
+                                                 (250, 4, 2, False), (257, 6, 3, True), (300, 8, 10, True), (400, 16, 2, True),
+                                                 (970, 9, 2, True), (1000, 9, 2, False), (2000, 32, 2, True), (256, 8, 2, False)])
+def test_padding_of_the_observation_count_is_skipped_bit_identically(eng, N, D, H, expect_skip):
+    """Round 5: N is padded to the GEMM's 128-row tiles; when at most six of the last row block's eight 16-row tiles hold
+    observations, that block goes to k_predict_gemm_tail (K steps and row tiles of the padding are not computed) and K(X*,X)
+    leaves the pad rows unwritten (option gemm_partial, default on).  Every EI value, the moments, the mean and the winner
+    equal the padded computation bit for bit -- and the oracle, as before."""
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(N, 4100, D, H, 900 + N, per_sec=True)
+    try:
+        eng.set_option("gemm_partial", 0)
+        a = eng.ei_grid(comp, vals, cand, hypers, want_draws=True, flags=2)
+        ma = [eng.get_moments(h) for h in range(H)]
+        assert eng.stat("last_step_skipped_padding") == 0
+        ap = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+        eng.set_option("gemm_partial", 1)
+        # (stale rows in the K* staging buffer must not matter: poison it with another problem's values first)
+        eng.ei_grid(comp[::-1].copy(), vals, 1.0 - cand, hypers)
+        b = eng.ei_grid(comp, vals, cand, hypers, want_draws=True, flags=2)
+        assert eng.stat("last_step_skipped_padding") == (1 if expect_skip else 0)
+        mb = [eng.get_moments(h) for h in range(H)]
+        bp = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+    finally:
+        eng.set_option("gemm_partial", -1)
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    for (m0, v0), (m1, v1) in zip(ma, mb):
+        assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+    assert ap[0] == bp[0] and np.array_equal(ap[3], bp[3])
+    if N <= 1000:
+        assert_ei_close(b[3], orc.ei_over_hypers(comp, cand, vals, hypers))
+
+
+def test_padding_skip_with_pending_fantasies_and_chunks(eng):
+    """... the same through the pending branch (the tail kernel's per-fantasy epilogue) and with several chunks and draw
+    groups per pass."""
+    comp, cand, vals, hypers = synthetic_problem(300, 6000, 5, 4, 907)
+    rs = np.random.RandomState(3)
+    fant = np.repeat(vals[None, :, None], 4, axis=0) + 0.05 * rs.randn(4, 300, 7)
+    bests = fant.min(axis=1)
+    out = []
+    try:
+        eng.set_option("kstar_budget_bytes", 384 * 1024 * 8)
+        for on in (0, 1):
+            eng.set_option("gemm_partial", on)
+            eng.set_observations(comp, vals); eng.set_hypers(hypers); eng.set_candidates(cand)
+            eng.factor(); eng.set_fantasies(fant, bests); eng.ei_run()
+            out.append((eng.best(), eng.ei_draws(), eng.stat("last_step_skipped_padding")))
+    finally:
+        eng.set_option("gemm_partial", -1)
+        eng.set_option("kstar_budget_bytes", 0)
+    assert out[0][2] == 0 and out[1][2] == 1
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    ref = np.stack([orc.compute_ei_fantasies(comp, cand[:500], hypers[h], fant[h], bests[h]) for h in range(4)], axis=1)
+    assert_ei_close(out[1][1][:500], ref)
+
+
 def test_step_argument_errors_leave_nothing_queued(eng):
     """spx_ei_step checks its flags BEFORE it queues the factorisation, and any later error exit of a pending
     step returns with the streams idle and without an unchecked factor."""
