@@ -645,8 +645,15 @@ int predict_gemm_padding_plan(int variant, int N, int Np)
 {
     if (!(variant == 0 || variant == 32)) return 0;
     const int nlive = (N + 15) / 16;
-    const int lt = nlive - 8 * (Np / BM - 1);      // live 16-row tiles of the last row block
-    return (lt >= 1 && lt <= 6) ? nlive : 0;
+    const int nrb = Np / BM;
+    const int lt = nlive - 8 * (nrb - 1);          // live 16-row tiles of the last row block
+    if (lt < 1 || lt > 6) return 0;
+    // The short block is a launch of its own in front of the others (it cannot share k_predict_gemm_tri's registers), which
+    // costs a launch boundary: about a tenth of the pass.  What it saves is (8 - lt) / 8 of the last block's (8 nrb)-step K
+    // loop out of 4 nrb (nrb + 1) steps in all = (8 - lt) / (4 (nrb + 1)).  Measured (profiles/r05_padding_skip.log: EI step,
+    // 20 000 x 10 / 100 000 x 10): N = 129 ... 160 -31 %, 257 -21 %, 300 -14 %, 400 -16 %, 900 -7 %, 1300 -5 %; but N = 600
+    // +-0, 1500 +6 %, 2000 +3 % where the saving is under a tenth.  Taken from 0.12 up.
+    return (25 * (8 - lt) >= 12 * (nrb + 1)) ? nlive : 0;
 }
 
 // Variants (spx_set_option "gemm_waves", per handle): 0 / 32 = production (k_predict_gemm_tri: 4 waves, LDS-DMA

@@ -639,10 +639,11 @@ def test_flat_covariance_launch_is_bit_identical(eng, tmp_path):
 
 @pytest.mark.parametrize("N,D,H,expect_skip", [(129, 3, 4, True), (150, 8, 3, True), (200, 5, 2, True), (230, 4, 2, False),
                                                  (250, 4, 2, False), (257, 6, 3, True), (300, 8, 10, True), (400, 16, 2, True),
-                                                 (970, 9, 2, True), (1000, 9, 2, False), (2000, 32, 2, True), (256, 8, 2, False)])
+                                                 (900, 9, 2, True), (1000, 9, 2, False), (1300, 12, 2, True), (2000, 32, 2, False),
+                                                 (256, 8, 2, False)])
 def test_padding_of_the_observation_count_is_skipped_bit_identically(eng, N, D, H, expect_skip):
     """Round 5: N is padded to the GEMM's 128-row tiles; when at most six of the last row block's eight 16-row tiles hold
-    observations, that block goes to k_predict_gemm_tail (K steps and row tiles of the padding are not computed) and K(X*,X)
+    observations (and that is at least 12 % of the pass: predict_gemm_padding_plan), that block goes to k_predict_gemm_tail (K steps and row tiles of the padding are not computed) and K(X*,X)
     leaves the pad rows unwritten (option gemm_partial, default on).  Every EI value, the moments, the mean and the winner
     equal the padded computation bit for bit -- and the oracle, as before."""
     comp, cand, vals, hypers, log_durs, th = synthetic_problem(N, 4100, D, H, 900 + N, per_sec=True)
@@ -667,6 +668,8 @@ def test_padding_of_the_observation_count_is_skipped_bit_identically(eng, N, D, 
     assert ap[0] == bp[0] and np.array_equal(ap[3], bp[3])
     if N <= 1000:
         assert_ei_close(b[3], orc.ei_over_hypers(comp, cand, vals, hypers))
+    else:
+        assert_ei_close(b[3][:600], orc.ei_over_hypers(comp, cand[:600], vals, hypers), rtol=1e-6)
 
 
 def test_padding_skip_with_pending_fantasies_and_chunks(eng):
