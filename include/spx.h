@@ -248,6 +248,8 @@ int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n);
  *   "flow_rearms"      times the handle went back to the one-launch form after a fallback;
  *   "flow_enabled"     1 while the one-launch factorisation is in use;   "n_cu"  compute units of the device;
  *   "last_step_fused"  1 if the last EI pass ran as a one-kernel form (no K* / beta in memory; no fantasies);
+ *   "last_step_skipped_padding"  1 if the last EI pass left the padding of N (to the GEMM's 128-row tiles) uncomputed
+ *                      (option "gemm_partial", default on: same bits, up to -31 % per pass just above a multiple of 128);
  *   "ranks_seen"       records in the table the last exchange reduced: the ranks of the attached communicator
  *                      (spx_comm_attach), the device slots of a multi-device handle, 1 otherwise.                  */
 int spx_get_stat(spx_handle* h, const char* name, int64_t* value);
@@ -278,6 +280,9 @@ const char* spx_timing_name(int i);
  * If an in-launch hand-off ever times out (its polls are bounded; never observed), the call is
  * repeated with one launch per block column, a warning is left in spx_last_error(), and the handle
  * stays in that form for "flow_rearm_after" clean factorisations (see spx_get_stat).
+ *   "gemm_partial"      N not a multiple of 128: the last 128-row block of the predict GEMM computes only the 16-row tiles
+ *                       that hold observations (k_predict_gemm_tail) and K(X*,X) does not write the pad rows (1, default,
+ *                       where it saves at least 12 % of the pass), or everything is computed on the padded size (0);
  *   "flow_rearm_after"  clean factorisations before the one-launch form is tried again (default 16, 0 = never);
  *   "flow_spin_limit"   polls a waiting workgroup makes before it gives up (0 = default, 2^20); tests set 1.
  * A kernel that is refused the dynamic LDS it asks for (hipFuncSetAttribute) makes the call fail with

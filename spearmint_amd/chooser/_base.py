@@ -339,6 +339,9 @@ class GPEIBase(object):
         self._lp_key = None     # the one-shot call below replaces the engine's resident observations
         idx, val, mean, draws = self.engine().ei_grid(comp, vals, cand, hyper_rows,
                                                       want_mean=True, want_draws=want_draws)
+        warning = self.engine().last_warning()    # (a hand-off time-out of the one-launch factorisation: results are unaffected)
+        if warning:
+            log("libspx " + warning)
         self.last_overall_ei = draws
         self.last_ei_mean = mean
         return idx, mean, draws

@@ -443,11 +443,19 @@ class Engine(object):
         return int(d.value), int(p.value)
 
     def last_warning(self):
-        """The warning a SUCCESSFUL call left in spx_last_error() (text starting with "warning:", include/spx.h:
-        spx_get_stat), or None."""
+        """The warning the data-flow factorisation's fallback left in spx_last_error() (text starting with "warning:",
+        include/spx.h: spx_get_stat) since the previous call of this method, or None.  (spx_last_error() is sticky; a new
+        warning is told from an old one by the handle's fallback counter.)"""
+        try:
+            n = self.stat("flow_fallbacks")
+        except (ValueError, SpxError):      # (a multi-device handle keeps its counters on the per-device handles)
+            return None
+        if n == self.__dict__.get("_warned_fallbacks", 0):
+            return None
+        self._warned_fallbacks = n
         msg = self._lib.spx_last_error()
         msg = msg.decode("utf-8", "replace") if isinstance(msg, bytes) else str(msg or "")
-        return msg if msg.startswith("warning:") else None
+        return msg if msg.startswith("warning:") else "warning: the data-flow factorisation fell back (%d so far)" % n
 
     def stat(self, name):
         """A counter of the handle: "flow_fallbacks", "flow_rearms", "flow_enabled", "n_cu", "last_step_fused", "ranks_seen" (include/spx.h: spx_get_stat)."""
