@@ -16,6 +16,9 @@ class OracleEngine(object):
     def set_covar(self, name):
         self.covar = name
 
+    def last_warning(self):
+        return None
+
     # -- resident-data mode (what the pending path of the choosers uses) ------------
     def set_observations(self, comp, vals):
         self.comp, self.vals, self.fant = np.asarray(comp, float), np.asarray(vals, float), None
