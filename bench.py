@@ -299,6 +299,21 @@ def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3):
     return out
 
 
+def emit_line(out):
+    """Rank 0: everything C stdio still holds goes out, THEN the one JSON line, and the process ends at once (no exit
+    handler prints behind it).  Other ranks end without flushing: under a launcher all ranks share one stdout."""
+    import ctypes
+    if out is not None:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
+
+
 def engine_class():
     """The engine the bench drives: spearmint_amd.engine.Engine (libspx.so, no fallback).  TEST HOOK, never set by the
     driver: SPX_BENCH_ENGINE="module:Class" substitutes another class with the same methods, so that the launch / rank /
@@ -466,8 +481,8 @@ def main_in_process(args):
             except Exception as e:      # a variant that cannot run here is reported, not fatal
                 out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         eng.set_partition(1)
-    print(json.dumps(out))
     eng.close()
+    emit_line(out)
 
 
 def main():
@@ -509,8 +524,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.next_baseline:
-        print(json.dumps(next_baseline()))
-        return
+        return emit_line(next_baseline())
     if args.in_process:
         return main_in_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -936,7 +950,7 @@ def main():
                                                       "this line was printed by the watchdog" % (args.lib_timeout, in_flight["key"]))
                     if in_flight["key"] and in_flight["key"] not in out:
                         out[in_flight["key"]] = {"error": "timed out after %d s (watchdog)" % args.lib_timeout, "n_gpus": world}
-                    print(json.dumps(out))
+                    sys.stdout.write(json.dumps(out) + "\n")
                     sys.stdout.flush()
                 os._exit(0)
 
@@ -954,14 +968,15 @@ def main():
             for name, ws in winners.items():
                 assert all(w[1:] == ws[0][1:] for w in ws), "collective variants disagree on the winner: %r" % (ws,)
 
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_candidates, args.cpu_reps)
-        print(json.dumps(out))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, args.cpu_candidates, args.cpu_reps)
+    # teardown FIRST, the line LAST: librccl (torch's, or the one libspx binds) prints a version banner through C stdio,
+    # which a pipe buffers until the process ends -- behind the JSON line if that were printed earlier
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
     eng.close()
+    emit_line(out if rank == 0 else None)
 
 
 if __name__ == "__main__":
