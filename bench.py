@@ -300,8 +300,9 @@ def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3):
 
 
 def emit_line(out):
-    """Rank 0: everything C stdio still holds goes out, THEN the one JSON line, and the process ends at once (no exit
-    handler prints behind it).  Other ranks end without flushing: under a launcher all ranks share one stdout."""
+    """Rank 0: everything C stdio still holds goes out FIRST (librccl prints a version banner through it, which a pipe
+    buffers until the process ends), then the one JSON line.  The other ranks' stdout was sent to stderr when they started
+    (main): under a launcher all ranks share one stdout.  The process then ends normally (a profiler's exit handlers run)."""
     import ctypes
     if out is not None:
         try:
@@ -310,8 +311,6 @@ def emit_line(out):
             pass
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
 
 
 def engine_class():
@@ -535,6 +534,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line would not describe the run" % (args.gpus, world))
+    if rank != 0:
+        os.dup2(2, 1)       # only rank 0 owns the shared stdout (nothing of another rank may land behind the JSON line)
     EngineCls, engine_name = engine_class()
 
     torch = None
