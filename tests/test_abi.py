@@ -257,3 +257,19 @@ def test_documents_name_files_that_exist():
             if not os.path.exists(os.path.join(root, m.group(1))):
                 missing.append((doc, m.group(1)))
     assert not missing, missing
+
+
+def test_the_stub_in_integration_md_is_python_and_names_only_abi_symbols():
+    """INTEGRATION.md section 2 is executed on the GPU box against the reference's own chooser class
+    (tests/test_gpu_h_reference_patch.py); here: the block parses, and every `_spx.<symbol>` it touches is declared in
+    include/spx.h (engine.ABI mirrors the header, test_header_and_binding_agree)."""
+    import ast
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. The ctypes stub"):]
+    block = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    ast.parse(block)
+    used = set(re.findall(r"_spx\.(spx_[a-z_]+)", block))
+    assert {"spx_create", "spx_ei_grid", "spx_last_error"} <= used
+    assert used <= set(engine.ABI), used - set(engine.ABI)
