@@ -737,7 +737,6 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
     int rc = check_run_flags(h, flags, h->nmodels);
     if (rc) return rc;
     if ((rc = ensure_init(h))) return rc;
-    if (rc) return rc;
     const int H = h->H, D = h->D, Dp = h->Dp, Np = h->Np, hs = 3 + D;
     const int64_t N = h->N, M = h->M, Mp = round_up(M, SPX_BN);
     const int nrb = Np / SPX_BM;
@@ -1344,7 +1343,7 @@ int spx_get_stat(spx_handle* h, const char* name, int64_t* value)
     else if (!strcmp(name, "ranks_seen")) *value = h->comm ? h->ranks_seen : 1;   // records in the table of the last all-gather (the ranks that took part)
     else if (!strcmp(name, "n_cu")) *value = h->n_cu;
     else if (!strcmp(name, "last_step_fused")) *value = h->last_fused ? 1 : 0; // the last EI pass ran k_ei_fused128
-    else if (!strcmp(name, "last_step_skipped_padding")) *value = h->last_skip_pad ? 1 : 0;   // ... skipped the padding of N (k_predict_gemm_tri<true>)
+    else if (!strcmp(name, "last_step_skipped_padding")) *value = h->last_skip_pad ? 1 : 0;   // ... skipped the padding of N (k_predict_gemm_tail)
     else return fail(SPX_ERR_ARG, "spx_get_stat: unknown statistic '%s'", name);
     return SPX_OK;
 }
