@@ -687,6 +687,12 @@ def main():
                     "flops_per_eval": flops_per_eval, "evals_per_launch": evals_per_launch,
                     "measured_over": "%d steps with per-launch HIP events on the library's stream" % ev_steps,
                     "dtype_peak_source": "AMD MI355X spec: 78.6 TFLOP/s fp64 matrix"}
+        # the WHOLE step against the same peak (N^2 solve + 2 N D sq-dist + 4 N moments + 12 N Matern flops per
+        # evaluation; factorisations, K(X*,X), finalize and argmax all inside the time): the driver's own clock can check this one
+        step_flops = float(N) * N + 2.0 * N * D + 16.0 * N
+        roofline["whole_step"] = {"flops_per_eval": step_flops, "achieved": step_flops * evals_per_step / (dt / args.steps) / 1e12,
+                                  "unit": "TFLOP/s", "frac": step_flops * evals_per_step / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                  "note": "algorithmic flops of one step / its wall time (the headline pass, no per-launch events)"}
         # what one launch has to move at least: its K(X*,X) columns once (8 N bytes per evaluation) + the live half of W
         Npad = -(-N // 128) * 128
         roofline["algorithmic_bytes"] = 8.0 * Npad * evals_per_launch + 8.0 * Npad * Npad / 2.0
