@@ -21,16 +21,21 @@ def kernel_table(so=None):
         if "amdgcn" not in f:
             continue
         notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(work, f)]).decode()
-        name = None
-        for line in notes.splitlines():
-            line = line.strip()
+        # one YAML list item per kernel, keys in alphabetical order: .agpr_count / .group_segment_fixed_size come BEFORE .name
+        cur = None
+        for raw in notes.splitlines():
+            line = raw.strip()
+            if line.startswith("- .") and not raw.startswith("      "):     # a new item of amdhsa.kernels (args are indented deeper)
+                cur = {}
+                line = line[2:]
+            if cur is None:
+                continue
             if line.startswith(".name:"):
-                name = line.split()[-1]
-                out[name] = {}
+                out[line.split()[-1]] = cur
             for key in (".vgpr_count", ".agpr_count", ".sgpr_count", ".private_segment_fixed_size", ".group_segment_fixed_size",
                         ".vgpr_spill_count", ".sgpr_spill_count"):
-                if name and line.startswith(key + ":"):
-                    out[name][key[1:]] = int(line.split()[-1])
+                if line.startswith(key + ":"):
+                    cur[key[1:]] = int(line.split()[-1])
     return out
 
 

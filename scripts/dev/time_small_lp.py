@@ -5,6 +5,10 @@ import numpy as np
 from spearmint_amd.engine import Engine
 from spearmint_amd.synthetic import synthetic_problem
 eng = Engine(0)
+if len(sys.argv) > 1:            # e.g. lean_merge=0
+    k, v = sys.argv[1].split("=")
+    eng.set_option(k, int(v))
+    print("option %s = %s" % (k, v))
 for N, D in ((10, 2), (20, 2), (50, 4), (64, 8), (65, 8), (128, 8), (129, 8), (192, 8), (200, 8), (256, 8), (320, 8)):
     line = "N=%3d D=%2d |" % (N, D)
     for H in (1, 6, 12):

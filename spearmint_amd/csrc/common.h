@@ -48,6 +48,10 @@ void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad,
                        double* xs /*[nh][n_pad][Dp]*/, double* sumsq /*[nh][n_pad]*/,
                        double* xs2 = nullptr /*optional: 2 * xs, same launch*/,
                        int* zero_ints = nullptr /*optional: n_zero ints cleared by the same launch*/, int n_zero = 0);
+// the log-likelihood path's prologue in ONE launch: launch_scale_rows (factor 1, with the doubled copy) + launch_lean_rhs_init
+void launch_lean_prologue(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp, const double* ls,
+                          int ls_stride, int nh, double* xs, double* sumsq, double* xs2, const double* vals,
+                          const double* htab, double* rhs, int* info, int* flags);
 void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const double* X2s,
                      const double* htab, double* K, int N, int Np, int Dp, int nh, bool tiled = false,
                      int kind = SPX_COV_MATERN52);

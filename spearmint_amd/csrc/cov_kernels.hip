@@ -26,23 +26,20 @@
 #define SR_DC 32   // feature columns per LDS pass
 // ROWS rows per workgroup: 256, or 64 when the launch would otherwise be a handful of workgroups (the log-likelihood
 // path: N = 2048 x 6 draws was 48 workgroups and 20 us; the arithmetic per row is the same either way)
+// (the body of k_scale_rows for row block bx of draw h: also the first part of k_lean_prologue)
 template <int ROWS>
-__global__ __launch_bounds__(256) void k_scale_rows(
+__device__ __forceinline__ void scale_rows_body(
     const double* __restrict__ x, int64_t n, int64_t n_pad, int D, int Dp,
     const double* __restrict__ ls, int ls_stride, double factor,
-    double* __restrict__ xs, double* __restrict__ sumsq, double* __restrict__ xs2, int* __restrict__ zero_ints, int n_zero)
+    double* __restrict__ xs, double* __restrict__ sumsq, double* __restrict__ xs2, int bx, int h)
 {
 #pragma clang fp contract(off)
-    // (the first kernel of a factorisation also clears its not-PD flags: one stream operation fewer per call)
-    if (zero_ints && blockIdx.x == 0 && blockIdx.y == 0)
-        for (int e = threadIdx.x; e < n_zero; e += 256) zero_ints[e] = 0;
     // ROWS rows per workgroup, staged through LDS so that both the read of x (rows of D doubles)
     // and the write of xs (rows of Dp doubles) are contiguous across the wave; each thread then
     // owns one row and accumulates its squared norm left to right.
     __shared__ double T[ROWS][SR_DC + 1];
     const int tid = threadIdx.x;
-    const int h = blockIdx.y;
-    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int64_t row0 = (int64_t)bx * ROWS;
     const int rows = (int)((n_pad - row0 < ROWS) ? (n_pad - row0) : ROWS);
     const int64_t row = row0 + tid;
     const double* lsh = ls + (size_t)h * ls_stride;
@@ -78,6 +75,69 @@ __global__ __launch_bounds__(256) void k_scale_rows(
         __syncthreads();
     }
     if (tid < rows) sumsq[(size_t)h * n_pad + row] = acc;
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_scale_rows(
+    const double* __restrict__ x, int64_t n, int64_t n_pad, int D, int Dp,
+    const double* __restrict__ ls, int ls_stride, double factor,
+    double* __restrict__ xs, double* __restrict__ sumsq, double* __restrict__ xs2, int* __restrict__ zero_ints, int n_zero)
+{
+    // (the first kernel of a factorisation also clears its not-PD flags: one stream operation fewer per call)
+    if (zero_ints && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int e = threadIdx.x; e < n_zero; e += 256) zero_ints[e] = 0;
+    scale_rows_body<ROWS>(x, n, n_pad, D, Dp, ls, ls_stride, factor, xs, sumsq, xs2, blockIdx.x, blockIdx.y);
+}
+
+// The log-likelihood path's two prologue launches as ONE (round 5): the first `nsb` workgroups of a draw scale the observations
+// (k_scale_rows<ROWS>, with the pre-doubled copy), the others write the right-hand-side block row in tile storage -- row 0 =
+// vals - mean, the rest 0 -- and clear the draw's not-PD flag and (k_lean_step_ps) its hand-off flags: k_lean_rhs_init's
+// body, value for value (chol_kernels.hip).  The two halves do not depend on each other; a call of spx_gp_logprob is a chain
+// of small dependent launches, and each one costs ~4 us whatever it does (profiles: scripts/dev/trace_small_lp.sh).
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_lean_prologue(
+    const double* __restrict__ x, int64_t n, int64_t n_pad, int D, int Dp,
+    const double* __restrict__ ls, int ls_stride,
+    double* __restrict__ xs, double* __restrict__ sumsq, double* __restrict__ xs2, int nsb,
+    const double* __restrict__ vals, const double* __restrict__ htab, double* __restrict__ rhs,
+    int* __restrict__ info, int* __restrict__ flags)
+{
+    const int h = blockIdx.y;
+    if ((int)blockIdx.x < nsb) {
+        scale_rows_body<ROWS>(x, n, n_pad, D, Dp, ls, ls_stride, 1.0, xs, sumsq, xs2, blockIdx.x, h);
+        return;
+    }
+    const int bx = blockIdx.x - nsb;
+    const int Np = (int)n_pad, N = (int)n;
+    const int idx = bx * 256 + threadIdx.x;      // over [nblk][4096]
+    if (bx == 0) {
+        if (threadIdx.x == 0) info[h] = 0;
+        if (flags && (int)threadIdx.x < Np / SPX_NB) flags[h * (Np / SPX_NB) + threadIdx.x] = 0;
+    }
+    if (idx >= SPX_NB * Np) return;
+    const int J = idx >> 12, e = idx & 4095;
+    const int t = (e >> 1) & 255, q = ((e >> 9) << 1) | (e & 1);   // thread slot, value q = nt * 4 + r
+    const int wave = t >> 6, lane = t & 63, r = q & 3, nt = q >> 2;
+    const int rowi = 16 * wave + (lane >> 4) + 4 * r, col = J * SPX_NB + 16 * nt + (lane & 15);
+    double v = 0.0;
+    if (rowi == 0 && col < N) v = vals[col] - htab[h * SPX_HT + 0];
+    rhs[(size_t)h * SPX_NB * Np + idx] = v;
+}
+
+void launch_lean_prologue(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp, const double* ls,
+                          int ls_stride, int nh, double* xs, double* sumsq, double* xs2, const double* vals,
+                          const double* htab, double* rhs, int* info, int* flags)
+{
+    const int nrhs = (int)((SPX_NB * n_pad + 255) / 256);
+    if (((n_pad + 255) / 256) * nh < 512) {
+        const int nsb = (int)((n_pad + 63) / 64);
+        hipLaunchKernelGGL(k_lean_prologue<64>, dim3(nsb + nrhs, nh), dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride, xs, sumsq,
+                           xs2, nsb, vals, htab, rhs, info, flags);
+    } else {
+        const int nsb = (int)((n_pad + 255) / 256);
+        hipLaunchKernelGGL(k_lean_prologue<256>, dim3(nsb + nrhs, nh), dim3(256), 0, s, x, n, n_pad, D, Dp, ls, ls_stride, xs, sumsq,
+                           xs2, nsb, vals, htab, rhs, info, flags);
+    }
 }
 
 void launch_scale_rows(hipStream_t s, const double* x, int64_t n, int64_t n_pad, int D, int Dp,

@@ -242,6 +242,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_ps = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
+    if (!strcmp(name, "lean_merge")) {     // log-likelihood path: observation scaling and the right-hand-side rows in one launch (1, default) or two (0)
+        h->lean_merge = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
     if (!strcmp(name, "gemm_partial")) {   // N not a multiple of 128: skip the padding's K steps / row tiles / K* rows (1, default) or compute them (0)
         h->gemm_partial = value < 0 ? -1 : (value != 0);
         return SPX_OK;
@@ -429,9 +433,14 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // (W^T's zeros above the diagonal blocks are written by k_trinv itself)
 
     const double* ls = h->hyp.d() + 3;
+    // The log-likelihood call is a chain of small dependent launches (~4 us each whatever they do): when nothing between
+    // them needs x / ls (k_lean_flow builds K(X,X) itself: the default), the scaling of the observations and the
+    // right-hand-side rows are ONE launch, further down where the right-hand side used to be written (option lean_merge).
+    const bool merged_prologue = lean && nh <= 32 && h->lean_merge != 0 && h->lean_flow != 0 && !h->flow_demoted && h->lean_flow_cov != 0;
     // x / ls and, in the same launch, the second operand pre-multiplied by 2 (gp.py:50; exact)
-    TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d(), h->X2s.d(),
-                                      zero_in_kernel ? nullptr : (int*)h->info.p, nh));
+    if (!merged_prologue)
+        TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d(), h->X2s.d(),
+                                          zero_in_kernel ? nullptr : (int*)h->info.p, nh));
     // (spx_ei_step: the candidate side of the EI pass needs x / ls and the hyper table, not the factor -- it starts here,
     // on the second stream, beside the factorisation)
     if (defer_sync && !lean) HIPCHK(hipEventRecord(h->ev_obs, s));
@@ -503,8 +512,12 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         rhs = h->rhs.d();
         if (rl) {
             if ((rc = h->diagL.reserve((size_t)nh * Np * 8))) return rc;
-            TIMED(ST_GAMMA_ALPHA, launch_lean_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh, (int*)h->info.p,
-                                                       ps ? (int*)h->ps_flags.p : nullptr));
+            if (merged_prologue)     // (implies flow and cov_in_flow: nothing before this point read x / ls)
+                TIMED(ST_SCALE, launch_lean_prologue(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, h->Xs.d(), h->s1.d(), h->X2s.d(),
+                                                     h->vals.d(), h->htab.d(), rhs, (int*)h->info.p, ps ? (int*)h->ps_flags.p : nullptr));
+            else
+                TIMED(ST_GAMMA_ALPHA, launch_lean_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh, (int*)h->info.p,
+                                                           ps ? (int*)h->ps_flags.p : nullptr));
         } else {
             TIMED(ST_GAMMA_ALPHA, launch_rhs_init(s, h->vals.d(), h->htab.d(), rhs, (int)N, Np, nh));
         }

@@ -144,6 +144,7 @@ struct spx_handle {
     int lean_np = 0;                                                // padded size of the last lean factorisation (a multiple of 64, not of 128)
     bool lean_tiled = false;                                        // the last lean factorisation used tile-major storage
     int lean_ps = -1;                                               // option "lean_ps": 0 / 1 / -1 = default (on)
+    int lean_merge = -1;                                            // option "lean_merge": scaling + right-hand side as one launch (k_lean_prologue) 1 / 0 / -1 = default (on)
     DevBuf ps_flags;                                                // k_lean_step_ps: progress of every diagonal block, [H][nblk]
     int lean_flow = -1;                                             // option "lean_flow": whole factorisation in one launch (k_lean_flow)
     int ei_fused = -1;                                              // option "ei_fused": N <= 128 without fantasies: the EI pass of a chunk as ONE kernel (k_ei_fused128) 1 / 0 / -1 = default (on)

@@ -698,6 +698,32 @@ def test_padding_skip_with_pending_fantasies_and_chunks(eng):
     assert_ei_close(out[1][1][:500], ref)
 
 
+@pytest.mark.parametrize("N,D,H", [(5, 2, 1), (64, 3, 6), (65, 8, 3), (200, 5, 12), (700, 9, 6), (2048, 16, 4), (300, 4, 40)])
+def test_merged_loglikelihood_prologue_is_bit_identical(eng, N, D, H):
+    """Round 5: the log-likelihood call's two prologue launches (observation scaling; right-hand-side rows + flag clearing) are
+    ONE (k_lean_prologue, option lean_merge).  Same values, bit for bit, as the two launches -- with a not-PD draw in the
+    batch, after a call with other sizes (stale right-hand sides / flags), and equal to the oracle."""
+    comp, cand, vals, hypers = synthetic_problem(N, 16, D, H, 4400 + N)
+    if H >= 3:
+        hypers[H // 2, 2] = -1.0                       # one draw that is not positive definite
+    other = synthetic_problem(N + 37, 16, D, max(1, H - 1), 11)
+    out = []
+    try:
+        for on in (0, 1):
+            eng.set_option("lean_merge", on)
+            eng.set_observations(other[0], other[2]); eng.set_hypers(other[3]); eng.gp_logprob()
+            eng.set_observations(comp, vals); eng.set_hypers(hypers)
+            out.append((eng.gp_logprob(), eng.not_pd_info()))
+    finally:
+        eng.set_option("lean_merge", -1)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    ref = np.array([orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:]) if hypers[h, 2] > 0 else -np.inf
+                    for h in range(H)])
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isneginf(out[1][0]), ~ok)
+    assert np.allclose(out[1][0][ok], ref[ok], rtol=1e-9, atol=1e-9 * N)
+
+
 def test_step_argument_errors_leave_nothing_queued(eng):
     """spx_ei_step checks its flags BEFORE it queues the factorisation, and any later error exit of a pending
     step returns with the streams idle and without an unchecked factor."""
