@@ -275,6 +275,7 @@ const char* spx_timing_name(int i);
  *                   diagonal block (1, default) or does not (0);
  *   "lean_flow_cov" k_lean_flow builds the tiles of K(X,X) itself (1, default) or reads k_cov's (0);
  *   "lean_lazy"     trailing updates one (0) or two (1) block columns at a time;
+ *   "lean_merge"    spx_gp_logprob: observation scaling and the right-hand-side rows in one launch (1, default) or two (0);
  *   "lean_ps"       1: the panel solve of a block column runs inside the update launch, handed the
  *                   inverse of the diagonal block behind its pivots; 0: a launch of its own.
  * If an in-launch hand-off ever times out (its polls are bounded; never observed), the call is
