@@ -30,6 +30,11 @@ Fixtures (all float64, ref = the reference's own functions):
                          refinement objective and seeded next() calls of the three choosers.
   chooser_two_calls.npz  next(), restart from the state pickle with a new chooser object, next() again.
   chooser_next_ml2.npz  GPEIChooser.next with mcmc_iters=0 (ML-II hypers, gp.py:181-292).
+  main_loop.npz    BASELINE config 1 through the reference's OWN primary driver: main.py's main() loop (GPEIChooser,
+                   examples/braninpy, --grid-size=1000 --grid-seed=1, mcmc_iters=10) and its attempt_dispatch under a
+                   fixed schedule with --max-concurrent=2 (GPEIOptChooser: pending branch, tuple return ->
+                   add_to_grid), run by tests/run_reference_main.py with the reference's own choosers: the job ids in
+                   dispatch order, their points and values as expt-grid.pkl holds them.
   ei_grad.npz      the refinement objective: GPEIOptChooser.grad_optimize_ei_over_hypers
                    without and with pending jobs, GPEIperSecChooser.grad_optimize_ei_over_hypers
                    (value + gradient at several points each).
@@ -583,10 +588,73 @@ def gen_ei_grad(mods, tmp):
     np.savez_compressed(os.path.join(OUT, "ei_grad.npz"), **out)
 
 
+MAIN_LOOP_RUNS = {
+    # tag: (mode, seed, schedule, main.py's own options)
+    "g": ("main", 5, "", ["--method=GPEIChooser", "--method-args=mcmc_iters=10", "--grid-size=1000", "--grid-seed=1",
+                          "--max-finished-jobs=8", "--polling-time=0.05"]),
+    "o": ("dispatch", 9, "d,w0,d,w1,d,r0,r1,d,w2,d,w3,r2,d,w4,r3,r4,d,w5,d,w6,r5,r6",
+          ["--method=GPEIOptChooser", "--method-args=mcmc_iters=10,burnin=20,grid_subset=5,use_multiprocessing=0",
+           "--grid-size=1000", "--grid-seed=1", "--max-concurrent=2"]),
+}
+
+
+def run_main_loop(tag, engine, workdir, zip_path=None):
+    """One run of tests/run_reference_main.py (a process of its own: the reference's main.py is a script, and its
+    protobuf module needs the pure-Python protobuf implementation selected before google.protobuf is imported).
+    Returns the JSON record."""
+    import json
+    import subprocess
+    import zipfile
+    mode, seed, sched, opts = MAIN_LOOP_RUNS[tag]
+    tree = os.path.join(workdir, "tree_%s_%s" % (tag, engine))
+    os.makedirs(tree)
+    if zip_path is None:
+        ref_py3.convert_main_tree(tree)
+    else:
+        with zipfile.ZipFile(zip_path) as z:
+            z.extractall(tree)
+    out = os.path.join(workdir, "rec_%s_%s.json" % (tag, engine))
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_main.py"), "--tree", tree, "--engine", engine,
+           "--mode", mode, "--seed", str(seed), "--out", out]
+    if sched:
+        cmd += ["--schedule", sched]
+    cmd += ["--"] + opts + [os.path.join(tree, "examples", "braninpy", "config.pb")]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    if p.returncode != 0:
+        raise RuntimeError("run_reference_main failed:\n" + p.stderr.decode()[-4000:])
+    rec = json.load(open(out))
+    rec["tree"], rec["stderr"] = tree, p.stderr.decode()
+    return rec
+
+
+def gen_main_loop(mods, tmp):
+    """SURVEY section 8 / BASELINE configs[0] through main.py itself, with the reference's own choosers in place."""
+    out = {}
+    for tag in sorted(MAIN_LOOP_RUNS):
+        rec = run_main_loop(tag, "reference", tmp)
+        order = rec["order"]
+        out[tag + "_order"] = np.array(order)
+        out[tag + "_points"] = np.array([rec["points"][str(j)] for j in order])
+        out[tag + "_values"] = np.array([rec["values"][str(j)] for j in order])
+        out[tag + "_grid_rows"] = rec["grid_rows"]
+        if rec["steps"] and isinstance(rec["steps"], list):
+            out[tag + "_step_job"] = np.array([-1 if s["job"] is None else s["job"] for s in rec["steps"]])
+            out[tag + "_step_npending"] = np.array([len(s["pending_before"]) for s in rec["steps"]])
+            out[tag + "_step_ncomplete"] = np.array([s["complete_before"] for s in rec["steps"]])
+        print("main loop", tag, "jobs", order, "best", float(np.min(out[tag + "_values"])))
+    np.savez_compressed(os.path.join(OUT, "main_loop.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1:                    # python oracle/make_golden.py gen_main_loop [...]: only these generators
+        os.makedirs(OUT, exist_ok=True)
+        mods = ref_py3.load()
+        for name in sys.argv[1:]:
+            globals()[name](mods, tempfile.mkdtemp(prefix="spx_golden_"))
+        return
     os.makedirs(OUT, exist_ok=True)
     mods = ref_py3.load()
-    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless, gen_two_calls, gen_trajectory, gen_covar):
+    for gen in (gen_ei_small, gen_pending, gen_persec, gen_branin_c1, gen_chooser_next, gen_chooser_next_pending, gen_slice, gen_ei_grad, gen_ml2, gen_noiseless, gen_two_calls, gen_trajectory, gen_covar, gen_main_loop):
         gen(mods, tempfile.mkdtemp(prefix="spx_golden_"))
     print("wrote", sorted(os.listdir(OUT)))
 
