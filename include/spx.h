@@ -187,6 +187,68 @@ int spx_ei_per_sec_grid(spx_handle* h,
                 int32_t flags, double* ei_mean_out, double* ei_draw_out,
                 int64_t* best_idx, double* best_val);
 
+/* ---- hyper-parameter slice sampling (the caller of spx_gp_logprob) -----------------------
+ * The reference's sample_hypers (spearmint/spearmint/chooser/GPEIChooser.py:268-346; GPEIOptChooser.py:621-706;
+ * GPEIperSecChooser.py:558-700) on util.slice_sample (spearmint/spearmint/util.py:34-93): per iteration ONE joint
+ * random-direction move over [mean, amp2, noise] and ONE component-wise sweep over the length scales, every
+ * log-probability a covariance build + Cholesky + solve.  spx_sample_hypers runs `n_iter` such iterations for the
+ * resident observations (spx_set_observations) inside the library: the control flow of the sampler, the priors, the
+ * speculative batching of its evaluations (each batch = one spx_gp_logprob call) and numpy's legacy random stream
+ * (MT19937: rand / randn / shuffle as numpy.random.RandomState produces them) are host C++ -- no interpreter between
+ * two GPU calls.  It is the SAME Markov chain as the reference's: the same points are accepted and the generator is
+ * left in the same state, draw for draw (tests/test_sampler_native.py pins it to the reference's golden trace).
+ *
+ *   cfg        which model is sampled and how deep the speculation goes (below)
+ *   rng        numpy.random.get_state() in, the state to numpy.random.set_state() out
+ *   hyper_io   [mean, noise, amp2, ls[0..D)] -- the chain's current point in, its last point out
+ *   rows_out   n_iter rows [mean, noise, amp2, ls...]: the point after every iteration (NULL: not wanted)
+ *   hist_io    12 doubles of bracket statistics the speculation learns from (zeros to start; keep between calls)
+ *   stats_out  {spx_gp_logprob calls, hyper rows evaluated, slice moves, moves that needed no call} (NULL ok)
+ *
+ * Errors (the iteration that failed is left as the reference leaves it: a finished joint move is applied, an
+ * unfinished sweep is not; `rng` is where the reference's generator would be; rows_out holds the iterations done;
+ * stats_out[4] = iterations completed):
+ *   SPX_ERR_NOT_PD      a covariance the sampler really evaluated was not positive definite (spla.cholesky raises)
+ *   SPX_ERR_SLICE_NAN   "Slice sampler got a NaN"          (util.py:59-61)
+ *   SPX_ERR_SLICE_ZERO  "Slice sampler shrank to zero!"    (util.py:68-69)                                            */
+#define SPX_ERR_SLICE_NAN  -4
+#define SPX_ERR_SLICE_ZERO -5
+typedef struct spx_rng_state {      /* numpy.random.get_state(): ('MT19937', key, pos, has_gauss, cached_gaussian)     */
+    uint32_t key[624];
+    int32_t  pos;
+    int32_t  has_gauss;
+    double   gauss;
+} spx_rng_state;
+typedef struct spx_sampler_cfg {
+    int32_t D;                    /* input dimensions = number of length scales                                        */
+    int32_t n_iter;               /* iterations: (joint move, length-scale sweep) each                                   */
+    int32_t noiseless;            /* 1: noise pinned to 1e-3 (GPEIChooser.py:270,326)                                    */
+    int32_t check_mean;           /* 1: -inf for a mean outside [vals_min, vals_max] (GPEIChooser.py:289-290)            */
+    int32_t amp2_prior_on_sqrt;   /* log-normal prior on sqrt(amp2) (GPEIOptChooser.py:668) instead of amp2 (:312)       */
+    int32_t lookahead;            /* step-out points per side and shrink proposals evaluated per call (>= 1)             */
+    int32_t follow_props;         /* cross-move speculation: proposals planned for the NEXT coordinate's move ...        */
+    int32_t follow_hyps;          /* ... under the hypotheses "this move accepts its 1st .. follow_hyps-th proposal"     */
+    int32_t max_rows;             /* hyper rows per spx_gp_logprob call the speculation may fill (<= 32 stays one launch) */
+    double  noise_scale;          /* horseshoe prior on the noise   (GPEIChooser.py:309)                                 */
+    double  amp2_scale;           /* log-normal prior on the amplitude                                                  */
+    double  max_ls;               /* top-hat prior on the length scales (GPEIChooser.py:279)                             */
+    double  vals_min, vals_max;   /* min / max of the observed values (the mean's support)                               */
+} spx_sampler_cfg;
+int spx_sample_hypers(spx_handle* h, const spx_sampler_cfg* cfg, spx_rng_state* rng, double* hyper_io,
+                      double* rows_out, double* hist_io /* 12 */, int64_t* stats_out /* 5 */);
+/* The same sampler on a caller-supplied log-likelihood: fn(ctx, rows[n_rows][3 + D], n_rows, lp_out[n_rows]) returns
+ * 0 and the data term -sum log diag L - 0.5 r'K^-1 r per row (-inf = not positive definite).  No handle, no GPU:
+ * how the CPU tests hold the sampler to the reference's chain, and how a host evaluator can be plugged in.  The
+ * choosers never use it -- their sampler is spx_sample_hypers on the GPU.                                              */
+typedef int (*spx_logprob_fn)(void* ctx, const double* rows, int32_t n_rows, double* lp_out);
+int spx_sample_hypers_with(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rng_state* rng,
+                           double* hyper_io, double* rows_out, double* hist_io, int64_t* stats_out);
+/* numpy's legacy generator, for tests: n_rand x rand(), then n_randn x randn(), then a shuffle of range(n_shuffle)
+ * (outputs may be NULL when their count is 0).                                                                         */
+int spx_rng_draw(spx_rng_state* rng, int32_t n_rand, double* rand_out, int32_t n_randn, double* randn_out,
+                 int32_t n_shuffle, int32_t* shuffle_out);
+
+
 /* ---- building blocks (per-stage parity tests, "next" rows) --------------- */
 /* After spx_factor: K + noise I (N x N, full symmetric), its lower Cholesky
  * factor L (N x N, strict upper = 0) and alpha = K^-1 (vals - mean) (N) of

@@ -61,12 +61,18 @@ class GPEIChooser(GPEIBase):
         # same computation; with pending ones its fantasy normals are drawn here,
         # right after the sample they belong to.
         rows, randn = [], []
-        for _ in range(self.mcmc_iters):
-            self.sample_hypers(comp, vals)
-            self._log_hypers()
-            rows.append(self.current_hyper_row())
-            if pend.shape[0] > 0:
+        if pend.shape[0] > 0:
+            for _ in range(self.mcmc_iters):
+                self.sample_hypers(comp, vals)
+                self._log_hypers()
+                rows.append(self.current_hyper_row())
                 # compute_ei's only use of the RNG (:238), at the same point of the stream
                 randn.append(npr.randn(pend.shape[0], self.pending_samples))
+        else:       # nothing else draws random numbers between two samples: all of them in one sampler call
+            def after(i):
+                self._log_hypers()
+                rows.append(self.current_hyper_row())
+            self._lp_key = None
+            self.sample_hypers_many(comp, vals, self.mcmc_iters, after)
         best, _, _ = self.ei_over_hypers_gpu(comp, pend, cand, vals, np.array(rows), randn=randn)
         return int(candidates[best])

@@ -102,6 +102,14 @@ class GPEIOptChooser(GPEIBase):
         GPEIBase.sample_hypers(self, comp, vals)
         self.hyper_samples.append((self.mean, self.noise, self.amp2, self.ls))
 
+    def _sample_and_collect(self, comp, vals, n_iter, prefix):
+        """n_iter x sample_hypers (one library call on the native path), each sample logged and appended like :621-628."""
+        def after(i):
+            self.hyper_samples.append((self.mean, self.noise, self.amp2, self.ls))
+            self._log_hypers(prefix % (i + 1, n_iter))
+        self._lp_key = None
+        self.sample_hypers_many(comp, vals, n_iter, after)
+
     def hyper_rows(self):
         return np.array([np.concatenate(([h[0], h[1], h[2]], np.asarray(h[3], dtype=float)))
                          for h in self.hyper_samples])
@@ -169,15 +177,11 @@ class GPEIOptChooser(GPEIBase):
                                       "ValueError; use GPEIChooser for ML-II hypers or mcmc_iters >= 1")
 
         if self.needs_burnin:
-            for it in range(self.burnin):
-                self.sample_hypers(comp, vals)
-                self._log_hypers("BURN %d/%d] " % (it + 1, self.burnin))
+            self._sample_and_collect(comp, vals, self.burnin, "BURN %d/%d] ")
             self.needs_burnin = False
 
         self.hyper_samples = []
-        for it in range(self.mcmc_iters):
-            self.sample_hypers(comp, vals)
-            self._log_hypers("%d/%d] " % (it + 1, self.mcmc_iters))
+        self._sample_and_collect(comp, vals, self.mcmc_iters, "%d/%d] ")
         self.dump_hypers()
         rows = self.hyper_rows()
 

@@ -77,11 +77,12 @@ class GPEIperSecChooser(GPEIBase):
     # -- sampling (:550-563) ---------------------------------------------------------
     def sample_hypers(self, comp, vals, durs):
         GPEIBase.sample_hypers(self, comp, vals)
-        self.time_mean, self.time_amp2, self.time_noise = self._draw_mean_amp_noise(
-            comp, durs, self.time_ls, [self.time_mean, self.time_amp2, self.time_noise],
-            self.time_noise_scale, self.time_amp2_scale, False, on_sqrt=True)
-        self.time_ls = self._draw_ls(comp, durs, self.time_mean, self.time_amp2, self.time_noise,
-                                     self.time_ls, self.time_max_ls)
+        states, err = self._sample_model(comp, durs, (self.time_mean, self.time_amp2, self.time_noise, self.time_ls),
+                                         self.time_noise_scale, self.time_amp2_scale, False, True, self.time_max_ls, 1)
+        if err is not None:
+            self.time_mean, self.time_amp2, self.time_noise, self.time_ls = err.state_at_error
+            raise err
+        self.time_mean, self.time_amp2, self.time_noise, self.time_ls = states[0]
         self.hyper_samples.append((self.mean, self.noise, self.amp2, self.ls))
         self.time_hyper_samples.append((self.time_mean, self.time_noise, self.time_amp2, self.time_ls))
 

@@ -44,10 +44,11 @@ class GPEIBase(object):
     amp2_prior_on_sqrt = False     # lognormal on sqrt(amp2) (Opt) vs amp2 (GPEIChooser)
     noiseless_checks_mean = True   # mean in [min, max] also in noiseless mode
     state_keys = ("dims", "ls", "amp2", "noise", "mean")
+    max_rows_per_call = 32         # spx_gp_logprob: one data-flow launch up to 32 hyper rows (spx_api.hip: do_factor, `rl`)
 
     def __init__(self, expt_dir, covar="Matern52", mcmc_iters=10, pending_samples=100,
                  noiseless=False, device=0, ndev=1, lib=None, gpu_logprob="auto", gpu_refine="auto",
-                 lookahead=6, gpu_sobol=0, **unused):
+                 lookahead="auto", follow="auto", sampler="native", gpu_sobol=0, **unused):
         if covar not in hostgp.COVARS:
             # the reference does getattr(gp, covar) here (GPEIChooser.py:52)
             raise AttributeError("no covariance function %r (gp.py has %s)" % (covar, ", ".join(hostgp.COVARS)))
@@ -76,7 +77,21 @@ class GPEIBase(object):
         # every size (scripts/dev/refine_threshold.py, 10 draws: one call for all 20 refinement points 0.06 ms from N = 8 to
         # N = 128; the host's per-draw models 0.74 ms per POINT at N = 8, 0.96 at 128): "auto" = GPU.
         self.gpu_refine = str(gpu_refine)
-        self.lookahead = max(1, int(lookahead))   # slice-sampler proposals evaluated speculatively per GPU call
+        # Depth of the slice sampler's speculation (util.slice_sample_batched): `lookahead` = step-out points per side and
+        # shrink proposals evaluated per GPU call; `follow` = "P:H": cross-move speculation -- the next coordinate move's
+        # edges, ladder and first P proposals under the hypotheses "this move accepts its 1st ... H-th proposal" ride in
+        # the same call.  What a row costs decides the depth: "auto" measures it once per problem size
+        # (_speculation_depth).  The Markov chain and the RNG stream are the reference's at every depth.
+        self.lookahead = lookahead if str(lookahead) == "auto" else max(1, int(lookahead))
+        self.follow = follow if str(follow) == "auto" else tuple(int(v) for v in str(follow).split(":"))
+        self._depth_cache = {}
+        # who runs the slice sampler on the GPU path: "native" = spx_sample_hypers (C++ inside libspx), "python" =
+        # util.slice_sample_batched around Engine.gp_logprob (round 5).  Same chain either way.
+        self.sampler = str(sampler)
+        if self.sampler not in ("native", "python"):
+            raise ValueError("sampler must be native or python (got %r)" % (sampler,))
+        self._native_hist = None
+        self.sampler_stats = {"calls": 0, "rows": 0, "moves": 0, "free_moves": 0}
         # opt-in: have the driver's ExperimentGrid build its Sobol candidate grid with the HIP
         # generator (bit-identical; spearmint-lite rebuilds the grid on every invocation)
         self.gpu_sobol = _as_bool(gpu_sobol)
@@ -108,6 +123,7 @@ class GPEIBase(object):
         d = dict(self.__dict__)
         d["_eng"] = None
         d["_slice_hist"] = {}     # batching statistics of THIS process: timing only, never part of a shipped copy
+        d["_native_hist"] = None
         return d
 
     # -- persistent state -------------------------------------------------------
@@ -162,6 +178,46 @@ class GPEIBase(object):
             return n >= int(os.environ.get("SPX_REFINE_MIN_N", "0"))
         return _as_bool(self.gpu_refine)
 
+    def _speculation_depth(self, comp, vals):
+        """(lookahead, (follow proposals, follow hypotheses)) for this problem size.
+
+        A log-likelihood call is latency-bound at Spearmint's operating sizes: on one MI355X a call costs the same for 1
+        and for 32 hyper rows up to N = 512 (0.046 ms at N = 64, 0.089 at 256, 0.146 -> 0.18 at 512;
+        profiles/r06_lean_rows.log), +40 % for 20 rows at N = 1024, and +8 % PER ROW at N = 2048.  So the depth follows
+        the measured marginal cost of a row, r = (t(17 rows) - t(1 row)) / (16 t(1 row)), taken once per (N, D) with the
+        chain's current hyper row (no random numbers are drawn; 2 x 3 calls):
+            r <= 0.004   rows are free:   lookahead 8, follow 4:2  (<= 32 rows per call, the one-launch limit)
+            r <= 0.03    cheap:           lookahead 8, follow 3:1
+            else         a row costs:     lookahead 6, no follow   (the depth tuned at N = 2048 in round 3)
+        Explicit `lookahead=` / `follow=` method arguments override either part."""
+        key = (comp.shape[0], comp.shape[1])
+        got = self._depth_cache.get(key)
+        if got is None:
+            la, fo = self.lookahead, self.follow
+            if la == "auto" or fo == "auto":
+                import time
+                eng = self.engine()
+                self._resident_observations(eng, comp, vals)
+                row = self.current_hyper_row()[None, :]
+                t = {}
+                for n in (1, 17):
+                    rows = np.repeat(row, n, axis=0)
+                    best = np.inf
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        eng.set_hypers(rows)
+                        eng.gp_logprob()
+                        best = min(best, time.perf_counter() - t0)
+                    t[n] = best
+                r = (t[17] - t[1]) / (16.0 * t[1])
+                auto = (8, (4, 2)) if r <= 0.004 else ((8, (3, 1)) if r <= 0.03 else (6, (0, 0)))
+                la = auto[0] if la == "auto" else la
+                fo = auto[1] if fo == "auto" else fo
+                self._depth_info = {"N": key[0], "D": key[1], "t1_ms": 1e3 * t[1], "t17_ms": 1e3 * t[17], "row_cost": r,
+                                    "lookahead": la, "follow": fo}
+            got = self._depth_cache[key] = (la, tuple(fo))
+        return got
+
     def data_logprob(self, comp, vals, mean, amp2, noise, ls):
         """-sum log diag L - 0.5 r'K^-1 r (GPEIChooser.py:281-285).  The slice sampler's
         control flow and RNG use stay on the host; only this O(N^3) term moves."""
@@ -197,41 +253,77 @@ class GPEIBase(object):
         closures do); `finish(x, data_lp)` adds the priors.  `to_rows(X[K, D]) -> list of K rows / None`, when
         given, does the same for a whole batch in a few array operations (a default-depth next() passes 16 000
         points through here, two thirds of them ladder points outside the priors' support)."""
-        # Data terms of the previous batch, keyed by the hyper row's bytes: every slice move starts by
-        # re-evaluating the point the previous move accepted (util.py:46), which that batch already
-        # holds -- the value is a deterministic function of the row, so it is reused, not recomputed.
-        memo = {}
+        # Data terms of the last two batches, keyed by the hyper row's bytes: every slice move starts by
+        # re-evaluating the point the previous move accepted (util.py:46), which an earlier batch already
+        # holds -- the value is a deterministic function of the row (and does not depend on which other rows share
+        # the call: tests/test_gpu_a_parity.py, batch-size bit invariance), so it is reused, not recomputed.  The same
+        # memo is what makes cross-move speculation work: a batch may carry `extras`, points the NEXT move will ask
+        # for if this one ends as guessed; that move then finds them here and needs no call of its own.
+        memo = [{}, {}]          # [current batch, the one before]
+        max_rows = self.max_rows_per_call
 
-        def many(xs):
-            rows, where, keys = [], [], []
-            got = {}
-            batch = to_rows(np.array(xs, dtype=float)) if (to_rows is not None and len(xs) > 1) else None
-            for k, x in enumerate(xs):
-                r = batch[k] if batch is not None else to_row(x)
-                if r is not None:
-                    key = np.asarray(r, dtype=float).tobytes()
-                    if key in memo:
-                        got[k] = memo[key]
-                    else:
-                        rows.append(r)
-                        where.append(k)
-                        keys.append(key)
+        def rows_of(xs):
+            if to_rows is not None and len(xs) > 1:
+                return to_rows(np.array(xs, dtype=float))
+            return [to_row(x) for x in xs]
+
+        def submit(xs, extras=()):
             values = [-np.inf] * len(xs)
             errors = [None] * len(xs)
-            fresh = {}
-            if rows:
-                lp, bad = self.data_logprob_many(comp, vals, np.array(rows))
-                for j, k in enumerate(where):
-                    fresh[keys[j]] = got[k] = (lp[j], bool(bad[j]))
-            for k, (lpk, badk) in got.items():
+            missing = {}
+
+            def settle(k, lpk, badk):
                 if badk:   # spla.cholesky would raise here -- only if the sampler really gets to it
                     errors[k] = np.linalg.LinAlgError("covariance not positive definite")
                 else:
                     values[k] = finish(xs[k], lpk)
-            if fresh:
-                memo.clear()
-                memo.update(fresh)
-            return util._LazyValues(values, errors)
+
+            for k, r in enumerate(rows_of(xs)):
+                if r is None:
+                    continue                      # -inf a priori, as the reference's closures return it
+                key = np.asarray(r, dtype=float).tobytes()
+                got = memo[0].get(key) or memo[1].get(key)
+                if got is not None:
+                    settle(k, got[0], got[1])
+                else:
+                    missing[k] = (key, r)
+            if not missing:
+                return util._LazyValues(values, errors)
+
+            def fill(lv):
+                rows, index = [], {}
+                for k, (key, r) in missing.items():
+                    if key not in index:
+                        index[key] = len(rows)
+                        rows.append(r)
+                room = max_rows - len(rows)
+                if room > 0 and len(extras):
+                    for r in rows_of(list(extras)):
+                        if room <= 0:
+                            break
+                        if r is None:
+                            continue
+                        key = np.asarray(r, dtype=float).tobytes()
+                        if key in index or key in memo[0] or key in memo[1]:
+                            continue
+                        index[key] = len(rows)
+                        rows.append(r)
+                        room -= 1
+                lp, bad = self.data_logprob_many(comp, vals, np.array(rows))
+                memo[1] = memo[0]
+                memo[0] = dict((key, (lp[j], bool(bad[j]))) for key, j in index.items())
+                for k, (key, r) in missing.items():
+                    j = index[key]
+                    settle(k, lp[j], bool(bad[j]))
+                lv.missing = ()
+            return util._LazyValues(values, errors, set(missing), fill)
+
+        def many(xs):            # the eager form: everything the batch names is evaluated now
+            lv = submit(xs)
+            if lv.missing:
+                lv.fill(lv)
+            return lv
+        many.submit = submit
         # what lets the sampler plan its speculative batches: where the log-probability is -inf whatever the data
         # say, and how the two ends of the bracket behaved in this chooser's earlier moves of the same kind
         many.admissible = admissible if admissible is not None else (lambda x: to_row(x) is not None)
@@ -282,7 +374,7 @@ class GPEIBase(object):
                 return None if ok is None else np.concatenate(([ok[0], ok[2], ok[1]], ls))
             new = util.slice_sample_batched(start, self._speculative_logprob(comp, vals, to_row, priors, kind="joint",
                                                                              admissible=lambda h: admissible(h) is not None),
-                                            compwise=False, lookahead=self.lookahead)
+                                            compwise=False, lookahead=self._speculation_depth(comp, vals)[0])
         else:
             new = util.slice_sample(start, logprob, compwise=False)
         return new[0], new[1], (1e-3 if noiseless else new[2])
@@ -306,19 +398,85 @@ class GPEIBase(object):
                 R[:, 0] = mean; R[:, 1] = noise; R[:, 2] = amp2
                 R[:, 3:] = X
                 return [R[k] if ok[k] else None for k in range(X.shape[0])]
+            la, fo = self._speculation_depth(comp, vals)
             return util.slice_sample_batched(ls, self._speculative_logprob(comp, vals, to_row, lambda x, lp: lp,
                                                                            admissible=inside, to_rows=to_rows),
-                                             compwise=True, lookahead=self.lookahead)
+                                             compwise=True, lookahead=la, follow=fo)
         return util.slice_sample(ls, logprob, compwise=True)
+
+    def _use_native_sampler(self, n):
+        return self.sampler == "native" and self._use_gpu_logprob(n) and hasattr(self.engine(), "sample_hypers")
+
+    def _sample_model(self, comp, vals, state, noise_scale, amp2_scale, noiseless, on_sqrt, max_ls, n_iter):
+        """`n_iter` iterations of the reference's sample_hypers for ONE GP (GPEIChooser.py:268-274: `_sample_noisy` /
+        `_sample_noiseless`, then `_sample_ls`): state = (mean, amp2, noise, ls) in; the list of states after each
+        iteration out, and the exception that ended the loop early (or None).  On the GPU path the whole loop is one call into libspx (spx_sample_hypers: the sampler's control
+        flow, priors, speculation and numpy's random stream in C++, one spx_gp_logprob per batch); `sampler=python` keeps
+        the round-5 form (util.slice_sample_batched around Engine.gp_logprob), tiny problems / gpu_logprob=0 the
+        reference's own serial form on the host.  All three are the same Markov chain."""
+        mean, amp2, noise, ls = state
+        if n_iter <= 0:
+            return [], None
+        if self._use_native_sampler(comp.shape[0]):
+            from ..engine import SamplerCfg
+            eng = self.engine()
+            self._resident_observations(eng, comp, vals)
+            la, fo = self._speculation_depth(comp, vals)
+            D = comp.shape[1]
+            cfg = SamplerCfg(D=D, n_iter=int(n_iter), noiseless=int(bool(noiseless)),
+                             check_mean=int((not noiseless) or self.noiseless_checks_mean),
+                             amp2_prior_on_sqrt=int(self.amp2_prior_on_sqrt if on_sqrt is None else on_sqrt),
+                             lookahead=int(la), follow_props=int(fo[0]), follow_hyps=int(fo[1]),
+                             max_rows=int(self.max_rows_per_call), noise_scale=float(noise_scale),
+                             amp2_scale=float(amp2_scale), max_ls=float(max_ls),
+                             vals_min=float(np.min(vals)), vals_max=float(np.max(vals)))
+            hyper = np.concatenate(([mean, noise, amp2], np.asarray(ls, dtype=float)))
+            if self._native_hist is None:
+                self._native_hist = np.zeros(12)
+            try:
+                rows, st = eng.sample_hypers(cfg, hyper, self._native_hist)
+                err = None
+            except Exception as ex:
+                st, rows = getattr(ex, "stats", None), getattr(ex, "rows_done", None)
+                if st is None:
+                    raise
+                err = ex                    # (the chain stays where the reference's exception leaves it)
+                err.state_at_error = (hyper[0], hyper[2], hyper[1], hyper[3:].copy())
+            for k in ("calls", "rows", "moves", "free_moves"):
+                self.sampler_stats[k] += st[k]
+            return [(r[0], r[2], r[1], r[3:].copy()) for r in rows], err
+        out = []
+        for _ in range(n_iter):
+            if noiseless:
+                noise = 1e-3
+            try:
+                mean, amp2, noise = self._draw_mean_amp_noise(comp, vals, ls, [mean, amp2, noise], noise_scale, amp2_scale,
+                                                              noiseless, on_sqrt=on_sqrt)
+                ls = self._draw_ls(comp, vals, mean, amp2, noise, ls, max_ls)
+            except Exception as ex:
+                ex.state_at_error = (mean, amp2, noise, ls)
+                return out, ex
+            out.append((mean, amp2, noise, ls))
+        return out, None
 
     def sample_hypers(self, comp, vals):
         self._lp_key = None       # whatever the engine holds from an earlier call is not trusted
+        self.sample_hypers_many(comp, vals, 1)
+
+    def sample_hypers_many(self, comp, vals, n_iter, after_each=None):
+        """n_iter iterations of sample_hypers; after_each(i) runs after every one with self.mean / amp2 / noise / ls set
+        to that iteration's sample (logging, collecting hyper_samples).  One library call on the native path."""
         if self.noiseless:
             self.noise = 1e-3
-        self.mean, self.amp2, self.noise = self._draw_mean_amp_noise(
-            comp, vals, self.ls, [self.mean, self.amp2, self.noise],
-            self.noise_scale, self.amp2_scale, self.noiseless)
-        self.ls = self._draw_ls(comp, vals, self.mean, self.amp2, self.noise, self.ls, self.max_ls)
+        states, err = self._sample_model(comp, vals, (self.mean, self.amp2, self.noise, self.ls), self.noise_scale,
+                                         self.amp2_scale, self.noiseless, None, self.max_ls, n_iter)
+        for i, (mean, amp2, noise, ls) in enumerate(states):
+            self.mean, self.amp2, self.noise, self.ls = mean, amp2, noise, ls
+            if after_each is not None:
+                after_each(i)
+        if err is not None:       # a finished joint move stays applied, an unfinished sweep does not -- as in the reference
+            self.mean, self.amp2, self.noise, self.ls = err.state_at_error
+            raise err
 
     def current_hyper_row(self):
         return np.concatenate(([self.mean, self.noise, self.amp2], np.asarray(self.ls, dtype=float)))

@@ -21,6 +21,8 @@ SPX_OK = 0
 SPX_ERR_ARG = -1
 SPX_ERR_HIP = -2
 SPX_ERR_NOT_PD = -3
+SPX_ERR_SLICE_NAN = -4
+SPX_ERR_SLICE_ZERO = -5
 
 COVAR = {"Matern52": 0, "Matern32": 1, "ARDSE": 2, "SE": 3}   # include/spx.h SPX_COVAR_*
 
@@ -32,6 +34,40 @@ FLAG_TIME_ONLY = 8
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int64_p = ctypes.POINTER(ctypes.c_int64)
 _c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+
+
+class RngState(ctypes.Structure):
+    """include/spx.h: spx_rng_state == numpy.random.get_state() of the legacy MT19937 generator."""
+    _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32), ("has_gauss", ctypes.c_int32),
+                ("gauss", ctypes.c_double)]
+
+    @classmethod
+    def from_numpy(cls, state=None):
+        import numpy.random as npr
+        st = npr.get_state() if state is None else state
+        if st[0] != "MT19937":
+            raise ValueError("the global numpy generator is not MT19937")
+        out = cls()
+        ctypes.memmove(out.key, np.ascontiguousarray(st[1], dtype=np.uint32).ctypes.data, 624 * 4)
+        out.pos, out.has_gauss, out.gauss = int(st[2]), int(st[3]), float(st[4])
+        return out
+
+    def to_numpy(self):
+        return ("MT19937", np.frombuffer(self.key, dtype=np.uint32).copy(), int(self.pos), int(self.has_gauss), float(self.gauss))
+
+
+class SamplerCfg(ctypes.Structure):
+    """include/spx.h: spx_sampler_cfg."""
+    _fields_ = [("D", ctypes.c_int32), ("n_iter", ctypes.c_int32), ("noiseless", ctypes.c_int32),
+                ("check_mean", ctypes.c_int32), ("amp2_prior_on_sqrt", ctypes.c_int32), ("lookahead", ctypes.c_int32),
+                ("follow_props", ctypes.c_int32), ("follow_hyps", ctypes.c_int32), ("max_rows", ctypes.c_int32),
+                ("noise_scale", ctypes.c_double), ("amp2_scale", ctypes.c_double), ("max_ls", ctypes.c_double),
+                ("vals_min", ctypes.c_double), ("vals_max", ctypes.c_double)]
+
+
+LOGPROB_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int32,
+                              ctypes.POINTER(ctypes.c_double))
 
 # every symbol include/spx.h declares: name -> (restype, argtypes)
 _vp = ctypes.c_void_p
@@ -76,6 +112,12 @@ ABI = {
     "spx_sobol_grid": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32, ctypes.c_int32,
                                       ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_int32, _c_double_p]),
     "spx_not_pd_info": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p]),
+    "spx_sample_hypers": (ctypes.c_int, [_vp, ctypes.POINTER(SamplerCfg), ctypes.POINTER(RngState), _c_double_p, _c_double_p,
+                                         _c_double_p, _c_int64_p]),
+    "spx_sample_hypers_with": (ctypes.c_int, [LOGPROB_FN, _vp, ctypes.POINTER(SamplerCfg), ctypes.POINTER(RngState),
+                                              _c_double_p, _c_double_p, _c_double_p, _c_int64_p]),
+    "spx_rng_draw": (ctypes.c_int, [ctypes.POINTER(RngState), ctypes.c_int32, _c_double_p, ctypes.c_int32, _c_double_p,
+                                    ctypes.c_int32, _c_int32_p]),
     "spx_get_timings": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p, ctypes.c_int]),
     "spx_get_stat": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "spx_timing_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -124,6 +166,57 @@ def _f64(a, shape=None):
 
 class SpxError(RuntimeError):
     pass
+
+
+def _sampler_result(lib, rc, rows, stats):
+    st = {"calls": int(stats[0]), "rows": int(stats[1]), "moves": int(stats[2]), "free_moves": int(stats[3]),
+          "iterations": int(stats[4])}
+    if rc == SPX_OK:
+        return rows, st
+    msg = lib.spx_last_error()
+    msg = msg.decode("utf-8", "replace") if isinstance(msg, bytes) else str(msg)
+    if rc == SPX_ERR_NOT_PD:
+        err = LinAlgError(msg)
+    elif rc in (SPX_ERR_SLICE_NAN, SPX_ERR_SLICE_ZERO):
+        from .util import SliceSamplerError
+        err = SliceSamplerError(msg)
+    elif rc == SPX_ERR_ARG:
+        err = ValueError(msg)
+    else:
+        err = SpxError(msg)
+    err.rows_done, err.stats = rows[:st["iterations"]], st
+    raise err
+
+
+def sample_hypers_with(logprob_rows, cfg, hyper, hist, rng_state=None, lib=None):
+    """spx_sample_hypers_with: the library's sampler on a caller-supplied log-likelihood
+    `logprob_rows(rows[n, 3 + D]) -> lp[n]` (-inf = not positive definite).  No GPU, no handle -- the CPU tests' way to
+    hold the native sampler to the reference's chain; the choosers never use it."""
+    import numpy.random as npr
+    lib = load_library(lib)
+    D = int(cfg.D)
+    failure = []
+
+    def cb(ctx, rows_p, n, out_p):
+        try:
+            rows = np.ctypeslib.as_array(rows_p, shape=(n, 3 + D)).copy()
+            lp = np.asarray(logprob_rows(rows), dtype=np.float64)
+            for i in range(n):
+                out_p[i] = lp[i]
+            return 0
+        except BaseException as ex:        # must not unwind through C
+            failure.append(ex)
+            return SPX_ERR_ARG
+    rng = RngState.from_numpy() if rng_state is None else rng_state
+    rows = np.empty((int(cfg.n_iter), 3 + D))
+    stats = np.zeros(5, dtype=np.int64)
+    rc = lib.spx_sample_hypers_with(LOGPROB_FN(cb), None, ctypes.byref(cfg), ctypes.byref(rng), _dp(hyper), _dp(rows),
+                                    _dp(hist), stats.ctypes.data_as(_c_int64_p))
+    if rng_state is None:
+        npr.set_state(rng.to_numpy())
+    if failure:
+        raise failure[0]
+    return _sampler_result(lib, rc, rows, stats)
 
 
 TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "host"}
@@ -393,6 +486,23 @@ class Engine(object):
             if draw >= 0:
                 raise LinAlgError("%d-th leading minor of the array is not positive definite" % (pivot + 1))
         return out
+
+    def sample_hypers(self, cfg, hyper, hist, rng_state=None):
+        """spx_sample_hypers on the resident observations: cfg.n_iter iterations of (joint move over [mean, amp2, noise],
+        component-wise sweep over the length scales) -- the reference's sample_hypers (GPEIChooser.py:268-346) -- inside
+        the library.  `hyper` = [mean, noise, amp2, ls...] (updated in place), `hist` = 12 doubles of bracket statistics
+        (updated in place).  The GLOBAL numpy generator supplies the random stream and is left where the reference's
+        would be (rng_state: use / update this RngState instead).  Returns (rows[n_iter, 3 + D], stats dict).  Raises
+        what the reference raises: LinAlgError (not positive definite), SliceSamplerError (NaN / shrank to zero)."""
+        import numpy.random as npr
+        rng = RngState.from_numpy() if rng_state is None else rng_state
+        rows = np.empty((int(cfg.n_iter), 3 + int(cfg.D)))
+        stats = np.zeros(5, dtype=np.int64)
+        rc = self._lib.spx_sample_hypers(self._h, ctypes.byref(cfg), ctypes.byref(rng), _dp(hyper), _dp(rows), _dp(hist),
+                                         stats.ctypes.data_as(_c_int64_p))
+        if rng_state is None:
+            npr.set_state(rng.to_numpy())
+        return _sampler_result(self._lib, rc, rows, stats)
 
     def ei_grad(self, point):
         """(-sum_h EI_h(x), gradient) at one point for the resident factorisation --

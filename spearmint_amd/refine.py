@@ -15,6 +15,15 @@ re-entrant fmin_l_bfgs_b: true for scipy >= 1.5 (the Fortran driver is called wi
 tested here on 1.15.3, bit-equal to the serial loop in tests/test_host_logic.py).  ``serial=True`` (or the
 environment variable SPX_REFINE_SERIAL=1) runs the instances one after the other instead.
 
+Lock-step form (round 6, the default where it applies): the Python loop of scipy's own driver (`_minimize_lbfgsb`: call
+`_lbfgsb.setulb` until it asks for f and g, evaluate, repeat) is run for all instances in ONE thread -- every instance is
+advanced to its next request, the waiting points go to the GPU in one call -- so no thread is started and no condition
+variable is passed around (at N = 256 the threads cost 21 of the refinement's 22 ms; the GPU calls 0.7 ms).  It drives the
+same compiled L-BFGS-B code with the same arguments, work arrays and defaults as `fmin_l_bfgs_b(..., bounds=bounds)`, but
+through scipy's private `_lbfgsb.setulb`, whose signature differs between scipy versions: it is used only if, in this
+process, it reproduces the public `fmin_l_bfgs_b` bit for bit on a fixed test problem (`lockstep_ok()`); otherwise the
+threaded form runs.  SPX_REFINE_THREADS=1 forces the threaded form.
+
 Python 2/3 common subset.
 """
 from __future__ import absolute_import, print_function
@@ -24,6 +33,94 @@ import threading
 
 import numpy as np
 import scipy.optimize as spo
+
+
+_LOCKSTEP = {}
+
+
+def _lockstep(eval_batch, pts, bounds):
+    """All L-BFGS-B instances advanced in one thread (scipy's `_minimize_lbfgsb` loop, per instance).  Returns the (P, D)
+    optima and the number of batched objective calls."""
+    from scipy.optimize import _lbfgsb
+    n_pts, n = pts.shape
+    m, factr, pgtol, maxls, maxfun, maxiter = 10, 1e7, 1e-5, 20, 15000, 15000      # fmin_l_bfgs_b's defaults
+    factr = (factr * np.finfo(float).eps) / np.finfo(float).eps                    # (as fmin_l_bfgs_b -> _minimize_lbfgsb pass it)
+    lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=float)
+    up = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=float)
+    nbd = np.zeros(n, np.int32)
+    low_bnd = np.zeros(n, np.float64)
+    upper_bnd = np.zeros(n, np.float64)
+    for i in range(n):
+        has_l, has_u = not np.isinf(lo[i]), not np.isinf(up[i])
+        if has_l:
+            low_bnd[i] = lo[i]
+        if has_u:
+            upper_bnd[i] = up[i]
+        nbd[i] = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}[(has_l, has_u)]
+    st = []
+    for i in range(n_pts):
+        st.append({"x": np.array(np.clip(pts[i], lo, up), dtype=np.float64), "f": 0.0, "g": np.zeros(n, np.float64),
+                   "wa": np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64), "iwa": np.zeros(3 * n, np.int32),
+                   "task": np.zeros(2, np.int32), "ln_task": np.zeros(2, np.int32), "lsave": np.zeros(4, np.int32),
+                   "isave": np.zeros(44, np.int32), "dsave": np.zeros(29, np.float64), "nfev": 0, "nit": 0})
+    live = list(range(n_pts))
+    calls = 0
+    while live:
+        need, still = [], []
+        for i in live:
+            s = st[i]
+            while True:
+                _lbfgsb.setulb(m, s["x"], low_bnd, upper_bnd, nbd, s["f"], s["g"], factr, pgtol, s["wa"], s["iwa"],
+                               s["task"], s["lsave"], s["isave"], s["dsave"], maxls, s["ln_task"])
+                t = s["task"][0]
+                if t == 3:                       # wants f and g at x
+                    need.append(i)
+                    still.append(i)
+                    break
+                if t == 1:                       # new iteration
+                    s["nit"] += 1
+                    if s["nit"] >= maxiter:
+                        s["task"][0], s["task"][1] = 5, 504
+                    elif s["nfev"] > maxfun:
+                        s["task"][0], s["task"][1] = 5, 502
+                    continue
+                break                            # converged / stopped
+        live = still
+        if need:
+            X = np.vstack([st[i]["x"] for i in need])
+            f, g = eval_batch(X)
+            calls += 1
+            for k, i in enumerate(need):
+                st[i]["f"] = float(f[k])
+                st[i]["g"] = np.array(g[k], dtype=np.float64, copy=True)
+                st[i]["nfev"] += 1
+    return np.vstack([s["x"] for s in st]), calls
+
+
+def lockstep_ok():
+    """True if, in this process, _lockstep reproduces scipy's public fmin_l_bfgs_b bit for bit on a fixed bounded test
+    problem (checked once; the private setulb interface is scipy-version specific)."""
+    if "ok" not in _LOCKSTEP:
+        try:
+            A = np.array([[3.0, 0.4, -0.2], [0.4, 2.0, 0.3], [-0.2, 0.3, 1.5]])
+            c = np.array([0.9, -0.3, 1.4])
+
+            def fg(x):
+                d = x - c
+                q = A.dot(d)
+                return float(0.5 * d.dot(q) + 0.1 * np.sum(np.cos(3.0 * x))), q - 0.3 * np.sin(3.0 * x)
+
+            def batch(X):
+                r = [fg(x) for x in X]
+                return np.array([v[0] for v in r]), np.array([v[1] for v in r])
+            pts = np.array([[0.2, 0.8, 0.5], [1.3, -0.2, 0.1], [0.0, 0.0, 1.0]])
+            bounds = [(0, 1)] * 3
+            got, _ = _lockstep(batch, pts, bounds)
+            want = np.array([spo.fmin_l_bfgs_b(fg, p.copy(), bounds=bounds, disp=0)[0] for p in pts])
+            _LOCKSTEP["ok"] = bool(np.array_equal(got, want))
+        except Exception:
+            _LOCKSTEP["ok"] = False
+    return _LOCKSTEP["ok"]
 
 
 def lbfgs_many(eval_batch, points, bounds, log=None, serial=None):
@@ -45,6 +142,11 @@ def lbfgs_many(eval_batch, points, bounds, log=None, serial=None):
                 f, g = eval_batch(np.asarray(x, dtype=float)[None, :])
                 return float(f[0]), np.array(g[0], dtype=float, copy=True)   # as the threaded path hands them over
             out[i, :] = spo.fmin_l_bfgs_b(one, pts[i, :].flatten(), bounds=bounds, disp=0)[0]
+        return out
+    if os.environ.get("SPX_REFINE_THREADS", "0") in ("", "0") and lockstep_ok():
+        out, calls = _lockstep(eval_batch, pts, bounds)
+        if log is not None:
+            log("refined %d points with %d batched objective calls" % (n, calls))
         return out
     cv = threading.Condition()
     state = {"live": n}

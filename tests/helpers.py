@@ -10,6 +10,7 @@ from oracle import gp_ei_oracle as orc
 class OracleEngine(object):
     def __init__(self, covar="Matern52"):
         self.calls = []
+        self.native_calls = []   # rows per log-likelihood batch of the native sampler
         self.fant = None
         self.covar = covar
 
@@ -57,6 +58,18 @@ class OracleEngine(object):
             except np.linalg.LinAlgError:
                 out[k] = -np.inf
         return out
+
+    def sample_hypers(self, cfg, hyper, hist, rng_state=None):
+        """Engine.sample_hypers on a box without a GPU: libspx's OWN sampler (spx_sample_hypers_with: the same C++ control
+        flow, priors, speculation and random stream the GPU path runs) with the oracle's data term as the log-likelihood
+        callback -- so the CPU tests drive the native sampler through the choosers exactly as the GPU path does."""
+        from spearmint_amd import engine as real
+
+        def rows_lp(rows):
+            self.set_hypers(rows)
+            self.native_calls.append(len(rows))
+            return self.gp_logprob()
+        return real.sample_hypers_with(rows_lp, cfg, hyper, hist, rng_state=rng_state)
 
     def get_factor(self, draw, want_K=True, want_L=True, want_alpha=True):
         return None, self.chols[draw], None

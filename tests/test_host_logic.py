@@ -354,6 +354,126 @@ def test_speculative_sampler_is_the_same_markov_chain(golden_dir):
         assert np.allclose(x, g["compwise"][k], rtol=1e-9)
 
 
+def test_cross_move_speculation_is_the_same_markov_chain_with_fewer_calls(golden_dir):
+    """util.slice_sample_batched(follow=(P, H)): the batch of one coordinate move also carries what the NEXT coordinate's
+    move will ask for if this one accepts its 1st ... H-th proposal (edges, ladder, first P proposals).  The evaluator is
+    lazy (`submit`): a move whose points are all known makes no call.  Same chain, same RNG state as util.slice_sample,
+    at every depth -- and fewer evaluator calls."""
+    g = _g(golden_dir, "slice_sampler.npz")
+    comp, vals = g["comp"], g["vals"]
+
+    def lp_ls(ls):
+        if np.any(ls < 0) or np.any(ls > 2):
+            return -np.inf
+        return hostgp.data_logprob(comp, vals, 0.1, 1.3, 1e-3, ls)
+
+    def lazy(lp, count):
+        memo = {}
+
+        def submit(xs, extras=()):
+            values, errors, missing = [None] * len(xs), [None] * len(xs), set()
+            for k, x in enumerate(xs):
+                key = np.asarray(x, dtype=float).tobytes()
+                if key in memo:
+                    values[k] = memo[key]
+                else:
+                    missing.add(k)
+            if not missing:
+                return util._LazyValues(values, errors)
+
+            def fill(lv):
+                count[0] += 1
+                count[1] += len(missing)
+                for k in missing:
+                    values[k] = memo[np.asarray(xs[k], dtype=float).tobytes()] = lp(xs[k])
+                for x in extras:
+                    key = np.asarray(x, dtype=float).tobytes()
+                    if key not in memo:
+                        memo[key] = lp(x)
+                        count[1] += 1
+                lv.missing = ()
+            return util._LazyValues(values, errors, missing, fill)
+
+        def many(xs):
+            lv = submit(xs)
+            if lv.missing:
+                lv.fill(lv)
+            return lv
+        many.submit = submit
+        many.admissible = lambda x: not (np.any(x < 0) or np.any(x > 2))
+        many.history = {}
+        return many
+
+    for sigma, la in ((1.0, 6), (1.0, 8), (0.4, 4), (3.0, 6)):
+        npr.seed(21); a = [np.ones(3)]
+        for _ in range(40):
+            a.append(util.slice_sample(a[-1], lp_ls, sigma=sigma, compwise=True))
+        sa = npr.get_state()
+        calls = {}
+        for follow in ((0, 0), (4, 2), (3, 1), (6, 3)):
+            count = [0, 0]
+            ev = lazy(lp_ls, count)
+            npr.seed(21); b = [np.ones(3)]
+            for _ in range(40):
+                b.append(util.slice_sample_batched(b[-1], ev, sigma=sigma, compwise=True, lookahead=la, follow=follow))
+            sb = npr.get_state()
+            assert np.array_equal(np.array(a), np.array(b)), (sigma, la, follow)
+            assert np.array_equal(sa[1], sb[1]) and sa[2] == sb[2]
+            calls[follow] = count[0]
+        assert calls[(4, 2)] < 0.9 * calls[(0, 0)] and calls[(6, 3)] < 0.8 * calls[(0, 0)], calls
+        assert calls[(6, 3)] <= calls[(3, 1)] <= calls[(0, 0)], calls
+    # the joint (random-direction) move ignores `follow`: nothing to follow into
+    ev = lazy(lp_ls, [0, 0])
+    npr.seed(4); x1 = util.slice_sample(np.ones(3), lp_ls, compwise=False); s1 = npr.get_state()
+    npr.seed(4); x2 = util.slice_sample_batched(np.ones(3), ev, compwise=False, lookahead=6, follow=(4, 2)); s2 = npr.get_state()
+    assert np.array_equal(x1, x2) and np.array_equal(s1[1], s2[1]) and s1[2] == s2[2]
+
+
+def test_chooser_adapter_serves_a_following_move_from_the_memo(tmp_path):
+    """chooser._speculative_logprob().submit: a batch with `extras` evaluates them in the same engine call (up to 32 rows);
+    a later batch made only of known rows makes no call; rows a priori outside the support never reach the engine; the
+    eager form many(xs) still evaluates at once.  Values equal the eager adapter's, bit for bit."""
+    from spearmint_amd.chooser import GPEIChooser
+    from tests.helpers import OracleEngine
+    rs = np.random.RandomState(5)
+    comp = rs.rand(25, 3); vals = rs.randn(25)
+    ch = GPEIChooser.init(str(tmp_path), "mcmc_iters=2,gpu_logprob=1")
+    ch._eng = OracleEngine()
+    calls = []
+    orig = ch.data_logprob_many
+
+    def counted(c, v, rows):
+        calls.append(len(rows))
+        return orig(c, v, rows)
+    ch.data_logprob_many = counted
+
+    def inside(x):
+        return not ((x < 0).any() or (x > 2.0).any())
+
+    def to_row(x):
+        return np.concatenate(([0.1, 1e-3, 1.2], x)) if inside(x) else None
+    xs = [rs.rand(3) * 1.5 for _ in range(4)] + [np.array([0.5, -0.1, 1.0])]
+    nxt = [rs.rand(3) * 1.5 for _ in range(3)] + [np.array([2.5, 0.1, 1.0])]
+    ev = ch._speculative_logprob(comp, vals, to_row, lambda x, lp: lp, admissible=inside)
+    lv = ev.submit(xs, nxt)
+    assert calls == [] and lv.missing == {0, 1, 2, 3}
+    assert lv.get(4) == -np.inf and calls == []              # a priori: no call
+    v0 = lv.get(0)
+    assert calls == [7] and not lv.missing                   # 4 of the batch + 3 admissible extras, one call
+    lv2 = ev.submit(nxt)
+    assert not lv2.missing and [lv2.get(k) for k in range(4)][3] == -np.inf and calls == [7]
+    eager = ch._speculative_logprob(comp, vals, to_row, lambda x, lp: lp, admissible=inside)
+    ve = eager(xs + nxt)
+    assert calls == [7, 7]
+    assert [lv.get(k) for k in range(5)] + [lv2.get(k) for k in range(4)] == list(ve.values) and v0 == ve.values[0]
+    # the row budget: 32 per call, the batch's own points first
+    many_x = [rs.rand(3) * 1.5 for _ in range(30)]
+    many_e = [rs.rand(3) * 1.5 for _ in range(10)]
+    lv3 = ev.submit(many_x, many_e)
+    lv3.get(0)
+    assert calls[-1] == 32
+
+
 # ---- batched local refinement (spearmint_amd/refine.py) ------------------------------------
 def test_lbfgs_many_equals_serial_scipy():
     """Every L-BFGS-B instance fed from batched objective calls returns exactly what a serial
@@ -384,6 +504,52 @@ def test_lbfgs_many_equals_serial_scipy():
     assert refine.lbfgs_many(f_many, np.zeros((0, 5)), bounds).shape == (0, 5)
     # the serial fallback (serial=True / SPX_REFINE_SERIAL=1, for a scipy whose fmin_l_bfgs_b is not re-entrant)
     assert np.array_equal(refine.lbfgs_many(f_many, pts, bounds, serial=True), got)
+
+
+def test_lockstep_refinement_equals_threads_and_serial_scipy(monkeypatch):
+    """The lock-step driver (round 6: scipy's own `_minimize_lbfgsb` loop run for all instances in one thread, default
+    where `lockstep_ok()`), the threaded form (SPX_REFINE_THREADS=1) and serial fmin_l_bfgs_b: the same optima bit for
+    bit, the same number of batched objective calls, also from starting points outside the bounds (scipy clips them), with
+    one-sided / missing bounds, and with an objective that fails."""
+    import threading
+    import scipy.optimize as spo
+    from spearmint_amd import refine
+    assert refine.lockstep_ok()          # scipy 1.15.3 here; a scipy with another setulb gets the threaded form
+    rs = np.random.RandomState(2)
+    D = 6
+    A = rs.randn(D, D); A = A @ A.T + np.eye(D)
+    c = rs.rand(D) * 1.4 - 0.2
+    n_batches = {}
+
+    def f_one(x):
+        r = x - c
+        return float(0.5 * r @ A @ r + 0.2 * np.sum(np.cos(4 * x))), A @ r - 0.8 * np.sin(4 * x)
+
+    def f_many(X):
+        n_batches[f_many.tag] = n_batches.get(f_many.tag, 0) + 1
+        fs, gs = zip(*[f_one(x) for x in X])
+        return np.array(fs), np.array(gs)
+
+    pts = rs.rand(20, D) * 1.3 - 0.15
+    for bounds in ([(0, 1)] * D, [(0, None), (None, 1), (None, None), (0.2, 0.9), (0, 1), (-1, 2)]):
+        threads_before = threading.active_count()
+        monkeypatch.setenv("SPX_REFINE_THREADS", "0")
+        f_many.tag = "lockstep"
+        a = refine.lbfgs_many(f_many, pts, bounds)
+        assert threading.active_count() == threads_before
+        monkeypatch.setenv("SPX_REFINE_THREADS", "1")
+        f_many.tag = "threads"
+        b = refine.lbfgs_many(f_many, pts, bounds)
+        ref = np.array([spo.fmin_l_bfgs_b(f_one, p.copy(), bounds=bounds, disp=0)[0] for p in pts])
+        assert np.array_equal(a, ref) and np.array_equal(b, ref)
+        assert n_batches["lockstep"] == n_batches["threads"]
+        n_batches.clear()
+    monkeypatch.setenv("SPX_REFINE_THREADS", "0")
+
+    def boom(X):
+        raise RuntimeError("objective failed")
+    with pytest.raises(RuntimeError):
+        refine.lbfgs_many(boom, pts, [(0, 1)] * D)
 
 
 def test_lbfgs_many_propagates_errors():
