@@ -7,7 +7,8 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Whichever way it is started, the JSON line's `n_gpus` is the number of ranks that TOOK PART in the collective
-(`ranks_seen`: the number of 16-byte records the all-gather returned) and the run fails instead of printing a line
+(`ranks_seen`: the size of the communicator the all-gather of the 16-byte records ran on -- one record per rank in its
+table; a check of the launch plumbing, not a separate measurement) and the run fails instead of printing a line
 whose `n_gpus` differs from --gpus.
 
 A "step" is one full pass of the hot path over one batch of synthetic input,
@@ -244,6 +245,45 @@ def cpu_baseline(w, m_cpu=20000, reps=2):
     return out
 
 
+def platform_info(eng, device):
+    """What the line was measured on (two boxes of one pool ran different ROCm / RCCL builds and differed by 2 %):
+    HIP runtime / driver versions and the device's clocks as the runtime reports them (through libspx: spx_get_stat), the
+    ROCm release of the image, torch's HIP build, and the clocks rocm-smi shows at the end of the run (bounded, optional)."""
+    import subprocess
+    info = {}
+    if eng is not None:
+        for key in ("hip_runtime_version", "hip_driver_version", "clock_khz", "mem_clock_khz", "wall_clock_khz", "n_cu",
+                    "l2_bytes", "mem_bus_bits"):
+            try:
+                info[key] = int(eng.stat(key))
+            except Exception as ex:
+                info[key] = "unavailable: %s" % ex
+        if isinstance(info.get("clock_khz"), int):
+            info["gpu_sclk_mhz_max"] = info["clock_khz"] / 1e3
+        if isinstance(info.get("mem_clock_khz"), int):
+            info["gpu_mclk_mhz_max"] = info["mem_clock_khz"] / 1e3
+    try:
+        info["rocm_version"] = open("/opt/rocm/.info/version").read().strip()
+    except Exception:
+        info["rocm_version"] = None
+    try:
+        import torch
+        info["torch"] = torch.__version__
+        info["torch_hip"] = torch.version.hip
+        info["device_name"] = torch.cuda.get_device_name(device)
+    except Exception:
+        pass
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--json"], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, timeout=20).stdout.decode()
+        card = list(json.loads(txt).values())[0]
+        info["rocm_smi_clocks_after_run"] = {k: v for k, v in card.items() if "clk" in k.lower() or "clock" in k.lower()}
+    except Exception as ex:
+        info["rocm_smi_clocks_after_run"] = "unavailable: %s" % type(ex).__name__
+    info["host_cpus"] = os.cpu_count()
+    return info
+
+
 def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3):
     """The cpu_baseline leg END TO END: one whole `GPEIOptChooser.next()` -- slice sampling of the
     hyper-parameters (burn-in + mcmc_iters draws), both EI passes over the grid, the L-BFGS-B refinement of the best 20
@@ -263,11 +303,12 @@ def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3):
     complete, candidates, pending = np.arange(N), np.arange(N, N + M), np.array([], dtype=int)
     args = "mcmc_iters=%d,burnin=%d,grid_subset=20,use_multiprocessing=0" % (mcmc_iters, burnin)
 
-    def run(mod):
-        ch = mod.init(tempfile.mkdtemp(prefix="spx_next_"), args)
+    def run(mod, extra=""):
+        ch = mod.init(tempfile.mkdtemp(prefix="spx_next_"), args + extra)
         npr.seed(seed)
         t0 = time.time()
         job = ch.next(grid, values, durations, candidates, pending, complete)
+        run.last = ch
         return time.time() - t0, job
 
     def show(job):
@@ -275,11 +316,29 @@ def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3):
 
     cold_s, job_a = run(ours_mod)
     warm_s, job_b = run(ours_mod)
+    warm_s2, job_b2 = run(ours_mod)
+    ch = run.last
+    st = dict(ch.sampler_stats)
+    by_rows = st.pop("calls_by_rows")
+    # the round-5 form of the same call on the same box, for attribution: the Python batched sampler at its fixed depth
+    # and the threaded refinement (SPX_REFINE_THREADS=1) -- the same proposal
+    os.environ["SPX_REFINE_THREADS"] = "1"
+    try:
+        run(ours_mod, ",sampler=python,lookahead=6,follow=0:0")
+        r5_s, job_r5 = run(ours_mod, ",sampler=python,lookahead=6,follow=0:0")
+    finally:
+        os.environ.pop("SPX_REFINE_THREADS", None)
     out = {"what": "one GPEIOptChooser.next() call: %d burn-in + %d slice-sampled draws, two EI passes over the grid, L-BFGS-B "
                    "refinement of 20 candidates" % (burnin, mcmc_iters),
            "config": {"N_obs": N, "grid_candidates": M, "D": D, "chooser_args": args, "seed": seed},
-           "ours": {"cold_s": cold_s, "warm_s": warm_s, "proposal": show(job_b), "engine": "libspx (HIP, fp64)"},
-           "ours_repeatable": show(job_a) == show(job_b)}
+           "ours": {"cold_s": cold_s, "warm_s": min(warm_s, warm_s2), "warm_runs_s": [warm_s, warm_s2], "proposal": show(job_b),
+                    "engine": "libspx (HIP, fp64)",
+                    "sampler": "spx_sample_hypers (native: C++ control flow + numpy MT19937 stream inside libspx), lock-step L-BFGS-B",
+                    "speculation_depth": getattr(ch, "_depth_info", None), "sampler_stats": st,
+                    "loglik_calls_by_rows": {str(r): c for r, c in enumerate(by_rows) if c},
+                    "round5_form_warm_s": r5_s, "round5_form": "sampler=python,lookahead=6,follow=0:0 + threaded refinement",
+                    "round5_form_same_proposal": show(job_r5) == show(job_b)},
+           "ours_repeatable": show(job_a) == show(job_b) == show(job_b2)}
     if mods is None:
         out["reference"] = None
         return out
@@ -681,7 +740,8 @@ def main():
                 traffic, traffic_src = pmc_traffic(args.workload)
         roofline = {"bound": "mfma", "kernel": "k_predict_gemm_tri", "achieved": achieved,
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "frac_vs_ubench": achieved / FP64_MFMA_MEASURED_TFLOPS,
+                    "traffic": traffic,
                     "traffic_source": traffic_src, "peak_measured_ubench": FP64_MFMA_MEASURED_TFLOPS,
                     "launches": gemm_n, "avg_launch_ms": gemm_ms / gemm_n,
                     "flops_per_eval": flops_per_eval, "evals_per_launch": evals_per_launch,
@@ -764,6 +824,7 @@ def main():
                        "collective": "libspx ncclAllGather (spx_comm_attach)" if lib_collective
                                      else "torch.distributed all_gather_into_tensor"},
             "roofline": roofline, "roofline_hbm": roofline_hbm,
+            "platform": platform_info(eng if engine_name == "libspx" else None, local_rank),
             "ms_per_step_with_events": dt_ev / ev_steps * 1e3,
             "stages_ms_per_step": {k: v[0] / ev_steps for k, v in tm.items() if v[1]},
             "best_index": best[0], "best_ei": best[1],

@@ -75,6 +75,13 @@ int  spx_create(int device_id, spx_handle** out);
  * communicator; the records then go through host memory (SPX_TRANSPORT_HOST).  librccl is
  * loaded when this is first called, not when libspx is.                                        */
 int  spx_create_multi(const int* device_ids, int32_t n_dev, spx_handle** out);
+/* The same with the transport of the records chosen by the caller instead of by the device list: SPX_TRANSPORT_NONE =
+ * as spx_create_multi decides (RCCL for distinct devices, host memory for repeated ids); SPX_TRANSPORT_HOST = host memory
+ * even between distinct GPUs; SPX_TRANSPORT_RCCL = the RCCL code path even for repeated ids (a real librccl refuses such
+ * a communicator -- for a stand-in library named by SPX_RCCL_LIB, tests/test_gpu_d2_fake_rccl.py).
+ * Environment read by the library (deployment hooks, nothing else): SPX_RCCL_LIB = the librccl to dlopen;
+ * SPX_RCCL_ANY_VERSION=1 waives the ncclGetVersion range check of the hand-declared binding.                        */
+int  spx_create_multi_transport(const int* device_ids, int32_t n_dev, int32_t transport, spx_handle** out);
 #define SPX_TRANSPORT_NONE 0   /* single-GPU handle: no collective                */
 #define SPX_TRANSPORT_RCCL 1   /* ncclAllGather over the devices' streams          */
 #define SPX_TRANSPORT_HOST 2   /* records staged through host memory               */
@@ -203,7 +210,8 @@ int spx_ei_per_sec_grid(spx_handle* h,
  *   hyper_io   [mean, noise, amp2, ls[0..D)] -- the chain's current point in, its last point out
  *   rows_out   n_iter rows [mean, noise, amp2, ls...]: the point after every iteration (NULL: not wanted)
  *   hist_io    12 doubles of bracket statistics the speculation learns from (zeros to start; keep between calls)
- *   stats_out  {spx_gp_logprob calls, hyper rows evaluated, slice moves, moves that needed no call} (NULL ok)
+ *   stats_out  SPX_SAMPLER_NSTATS values: {spx_gp_logprob calls, hyper rows evaluated, slice moves, moves that needed no
+ *              call, iterations completed, then calls by number of hyper rows: [5 + r] for r = 0 .. 32, [38] beyond} (NULL ok)
  *
  * Errors (the iteration that failed is left as the reference leaves it: a finished joint move is applied, an
  * unfinished sweep is not; `rng` is where the reference's generator would be; rows_out holds the iterations done;
@@ -211,6 +219,7 @@ int spx_ei_per_sec_grid(spx_handle* h,
  *   SPX_ERR_NOT_PD      a covariance the sampler really evaluated was not positive definite (spla.cholesky raises)
  *   SPX_ERR_SLICE_NAN   "Slice sampler got a NaN"          (util.py:59-61)
  *   SPX_ERR_SLICE_ZERO  "Slice sampler shrank to zero!"    (util.py:68-69)                                            */
+#define SPX_SAMPLER_NSTATS 39
 #define SPX_ERR_SLICE_NAN  -4
 #define SPX_ERR_SLICE_ZERO -5
 typedef struct spx_rng_state {      /* numpy.random.get_state(): ('MT19937', key, pos, has_gauss, cached_gaussian)     */
@@ -235,7 +244,7 @@ typedef struct spx_sampler_cfg {
     double  vals_min, vals_max;   /* min / max of the observed values (the mean's support)                               */
 } spx_sampler_cfg;
 int spx_sample_hypers(spx_handle* h, const spx_sampler_cfg* cfg, spx_rng_state* rng, double* hyper_io,
-                      double* rows_out, double* hist_io /* 12 */, int64_t* stats_out /* 5 */);
+                      double* rows_out, double* hist_io /* 12 */, int64_t* stats_out /* SPX_SAMPLER_NSTATS */);
 /* The same sampler on a caller-supplied log-likelihood: fn(ctx, rows[n_rows][3 + D], n_rows, lp_out[n_rows]) returns
  * 0 and the data term -sum log diag L - 0.5 r'K^-1 r per row (-inf = not positive definite).  No handle, no GPU:
  * how the CPU tests hold the sampler to the reference's chain, and how a host evaluator can be plugged in.  The
@@ -312,7 +321,7 @@ int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n);
  *   "last_step_fused"  1 if the last EI pass ran as a one-kernel form (no K* / beta in memory; no fantasies);
  *   "last_step_skipped_padding"  1 if the last EI pass left the padding of N (to the GEMM's 128-row tiles) uncomputed
  *                      (option "gemm_partial", default on: same bits, up to -31 % per pass just above a multiple of 128);
- *   "ranks_seen"       records in the table the last exchange reduced: the ranks of the attached communicator
+ *   "ranks_seen"       size of the communicator the last exchange ran on (one record per rank in its table): the ranks of the attached communicator
  *                      (spx_comm_attach), the device slots of a multi-device handle, 1 otherwise.                  */
 int spx_get_stat(spx_handle* h, const char* name, int64_t* value);
 const char* spx_timing_name(int i);

@@ -12,7 +12,7 @@ out=gpurun_out/${tag}_pytest_gpu.log
   echo "sources sha256 $(cat spearmint_amd/csrc/*.hip spearmint_amd/csrc/*.h include/spx.h | sha256sum | cut -d' ' -f1)"
   echo "date $(date -u +%FT%TZ)  host $(hostname)  $(/opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 gfx9 | tr -s ' ')"
 } > $out
-python -m pytest tests -m gpu -q -p no:cacheprovider -W ignore -rfEs --durations=8 2>&1 | grep -v "amdgpu.ids" >> $out
+SPX_FULL_C3=1 python -m pytest tests -m gpu -q -p no:cacheprovider -W ignore -rfEs --durations=8 2>&1 | grep -v "amdgpu.ids" >> $out
 rc=${PIPESTATUS[0]}
 echo "pytest rc $rc" >> $out
 tail -25 $out

@@ -91,7 +91,7 @@ class GPEIBase(object):
         if self.sampler not in ("native", "python"):
             raise ValueError("sampler must be native or python (got %r)" % (sampler,))
         self._native_hist = None
-        self.sampler_stats = {"calls": 0, "rows": 0, "moves": 0, "free_moves": 0}
+        self.sampler_stats = {"calls": 0, "rows": 0, "moves": 0, "free_moves": 0, "calls_by_rows": [0] * 34}
         # opt-in: have the driver's ExperimentGrid build its Sobol candidate grid with the HIP
         # generator (bit-identical; spearmint-lite rebuilds the grid on every invocation)
         self.gpu_sobol = _as_bool(gpu_sobol)
@@ -185,10 +185,13 @@ class GPEIBase(object):
         and for 32 hyper rows up to N = 512 (0.046 ms at N = 64, 0.089 at 256, 0.146 -> 0.18 at 512;
         profiles/r06_lean_rows.log), +40 % for 20 rows at N = 1024, and +8 % PER ROW at N = 2048.  So the depth follows
         the measured marginal cost of a row, r = (t(17 rows) - t(1 row)) / (16 t(1 row)), taken once per (N, D) with the
-        chain's current hyper row (no random numbers are drawn; 2 x 3 calls):
-            r <= 0.004   rows are free:   lookahead 8, follow 4:2  (<= 32 rows per call, the one-launch limit)
-            r <= 0.03    cheap:           lookahead 8, follow 3:1
-            else         a row costs:     lookahead 6, no follow   (the depth tuned at N = 2048 in round 3)
+        chain's current hyper row (no random numbers are drawn; 2 x 3 calls).  Measured with the native sampler
+        (profiles/r06_next_phases.log; next() at N = 64 / 256 / 1024 / 2048):
+            r <= 0.01 and a call >= 65 us   lookahead 8, follow 6:3   (N = 256: 252 -> 180 calls, next() 31.3 -> 26.5 ms)
+            r <= 0.03                       lookahead 8, follow 4:2   (N = 64: 280 -> 207 calls; N = 1024: 445 -> 341,
+                                            139 -> 122 ms; below 65 us per call the host's ~0.6 us per extra row decides)
+            else                            lookahead 6, no follow    (N = 2048: a row costs 12 % of a call)
+        (<= 32 rows per call either way: the one-launch limit of spx_gp_logprob.)
         Explicit `lookahead=` / `follow=` method arguments override either part."""
         key = (comp.shape[0], comp.shape[1])
         got = self._depth_cache.get(key)
@@ -210,7 +213,7 @@ class GPEIBase(object):
                         best = min(best, time.perf_counter() - t0)
                     t[n] = best
                 r = (t[17] - t[1]) / (16.0 * t[1])
-                auto = (8, (4, 2)) if r <= 0.004 else ((8, (3, 1)) if r <= 0.03 else (6, (0, 0)))
+                auto = (8, (6, 3)) if (r <= 0.01 and t[1] >= 65e-6) else ((8, (4, 2)) if r <= 0.03 else (6, (0, 0)))
                 la = auto[0] if la == "auto" else la
                 fo = auto[1] if fo == "auto" else fo
                 self._depth_info = {"N": key[0], "D": key[1], "t1_ms": 1e3 * t[1], "t17_ms": 1e3 * t[17], "row_cost": r,
@@ -444,6 +447,7 @@ class GPEIBase(object):
                 err.state_at_error = (hyper[0], hyper[2], hyper[1], hyper[3:].copy())
             for k in ("calls", "rows", "moves", "free_moves"):
                 self.sampler_stats[k] += st[k]
+            self.sampler_stats["calls_by_rows"] = [a + b for a, b in zip(self.sampler_stats["calls_by_rows"], st["calls_by_rows"])]
             return [(r[0], r[2], r[1], r[3:].copy()) for r in rows], err
         out = []
         for _ in range(n_iter):
@@ -477,6 +481,15 @@ class GPEIBase(object):
         if err is not None:       # a finished joint move stays applied, an unfinished sweep does not -- as in the reference
             self.mean, self.amp2, self.noise, self.ls = err.state_at_error
             raise err
+        self._log_engine_warning()
+
+    def _log_engine_warning(self):
+        """The log-likelihood calls are the main users of the one-launch factorisation: its fallback warning (a hand-off
+        time-out; results unaffected) is polled after the sampler too, not only after an EI pass."""
+        if self._eng is not None and hasattr(self._eng, "last_warning"):
+            warning = self._eng.last_warning()
+            if warning:
+                log("libspx " + warning)
 
     def current_hyper_row(self):
         return np.concatenate(([self.mean, self.noise, self.amp2], np.asarray(self.ls, dtype=float)))

@@ -57,7 +57,8 @@ void launch_cov_self(hipStream_t s, const double* Xs, const double* s1, const do
                      int kind = SPX_COV_MATERN52);
 void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                       const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
-                      int Dp, int nh, int kind = SPX_COV_MATERN52, int live_rows = 0 /*> 0: rows from here on are NOT written*/);
+                      int Dp, int nh, int kind = SPX_COV_MATERN52, int live_rows = 0 /*> 0: rows from here on are NOT written*/,
+                      bool allow_flat = true /*false: always the 3-D grid (option cov_flat)*/);
 void launch_cross_mean(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                        const double* s2, const double* htab, const double* alpha, double* out,
                        int N, int Np, int Mc, int Dp, int nh, int kind = SPX_COV_MATERN52);

@@ -357,21 +357,23 @@ __global__ __launch_bounds__(256, 2) void k_cov_flat(
 template <int MODE, int KIND>
 static void launch_cov_kind(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                             const double* s2, const double* htab, const double* alpha, double* out,
-                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo, int live_rows)
+                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo, int live_rows, bool allow_flat)
 {
     const int Q = Dp / 4;
     int rows_per_wg = (Np >= 1024) ? 512 : ((Np >= 256) ? 256 : 128);
-    static const char* rpw = getenv("SPX_COV_RPW");   // dev
+#ifdef SPX_DEV_KNOBS   // (make DEV_KNOBS=1: development builds only; the shipped library reads no SPX_COV_* variable)
+    static const char* rpw = getenv("SPX_COV_RPW");
     if (rpw && MODE == 3) rows_per_wg = atoi(rpw);
+#endif
     const int row_top = (MODE == 0 && live_rows > 0) ? live_rows : Np;     // (MODE 0: rows past live_rows are left alone)
     dim3 grid(Mc / 64, (MODE == 2) ? 1 : (row_top + rows_per_wg - 1) / rows_per_wg, nh);
     dim3 block(256);
     if (MODE == 0) {
         // a launch of several residency rounds: whole rounds, equal shares (k_cov_flat); `places` = 2 workgroups per CU
-        static const char* flat_env = getenv("SPX_COV_FLAT");   // dev: 0 = always the 3-D grid
+        // (handle option "cov_flat" = 0: always the 3-D grid -- bit-identical, kept for A/B runs and its test)
         const int64_t places = 2 * (int64_t)spx_cov_cus(), wgs = (int64_t)grid.x * grid.y * grid.z;
         const int64_t units = (int64_t)nh * (Mc / 64) * (((live_rows > 0 ? live_rows : Np) + 127) / 128);
-        if (wgs > places && units >= 4 * places && !(flat_env && *flat_env == '0')) {
+        if (wgs > places && units >= 4 * places && allow_flat) {
             // shares of at most 16 units (2048 rows x 64 columns): as many whole rounds as that takes
             const int64_t rounds = (units + 16 * places - 1) / (16 * places);
             const dim3 fgrid((unsigned)(places * rounds));
@@ -398,21 +400,21 @@ static void launch_cov_kind(hipStream_t s, const double* Xs, const double* s1, c
 template <int MODE>
 static void launch_cov_mode(hipStream_t s, int kind, const double* Xs, const double* s1, const double* Cs,
                             const double* s2, const double* htab, const double* alpha, double* out,
-                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo, int live_rows = 0)
+                            int N, int Np, int Mc, int Dp, int nh, int64_t ldo, int live_rows = 0, bool allow_flat = true)
 {
     if (kind == SPX_COV_MATERN32)
-        launch_cov_kind<MODE, SPX_COV_MATERN32>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows);
+        launch_cov_kind<MODE, SPX_COV_MATERN32>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows, allow_flat);
     else if (kind == SPX_COV_ARDSE)
-        launch_cov_kind<MODE, SPX_COV_ARDSE>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows);
+        launch_cov_kind<MODE, SPX_COV_ARDSE>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows, allow_flat);
     else
-        launch_cov_kind<MODE, SPX_COV_MATERN52>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows);
+        launch_cov_kind<MODE, SPX_COV_MATERN52>(s, Xs, s1, Cs, s2, htab, alpha, out, N, Np, Mc, Dp, nh, ldo, live_rows, allow_flat);
 }
 
 void launch_cov_cross(hipStream_t s, const double* Xs, const double* s1, const double* Cs,
                       const double* s2, const double* htab, double* Kst, int N, int Np, int Mc,
-                      int Dp, int nh, int kind, int live_rows)
+                      int Dp, int nh, int kind, int live_rows, bool allow_flat)
 {
-    launch_cov_mode<0>(s, kind, Xs, s1, Cs, s2, htab, nullptr, Kst, N, Np, Mc, Dp, nh, Mc, live_rows);
+    launch_cov_mode<0>(s, kind, Xs, s1, Cs, s2, htab, nullptr, Kst, N, Np, Mc, Dp, nh, Mc, live_rows, allow_flat);
 }
 
 // X2s = 2 * Xs (the reference multiplies the second operand by 2, gp.py:50)

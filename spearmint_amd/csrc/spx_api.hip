@@ -48,6 +48,12 @@ int spx_fail(int code, const char* fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     spx_err_slot() = buf;
+    // a hipFuncSetAttribute refusal noted during THIS call (SPX_LDS_ATTR) and not yet reported by a LAUNCHCHK must not
+    // outlive the call: the next launch check on this thread, for another handle, would name a kernel it never launched
+    if (!spx_attr_err_slot().empty()) {
+        spx_err_slot() += " [also: " + spx_attr_err_slot() + "]";
+        spx_attr_err_slot().clear();
+    }
     return code;
 }
 
@@ -244,6 +250,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_merge")) {     // log-likelihood path: observation scaling and the right-hand-side rows in one launch (1, default) or two (0)
         h->lean_merge = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "cov_flat")) {       // K(X*,X) launches of several residency rounds: equal contiguous shares (k_cov_flat; 1, default) or the 3-D grid (0)
+        h->cov_flat = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
     if (!strcmp(name, "gemm_partial")) {   // N not a multiple of 128: skip the padding's K steps / row tiles / K* rows (1, default) or compute them (0)
@@ -761,12 +771,19 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
         // plan's own 28 672-candidate chunks fit; the 256 MB of earlier rounds cut them to 9 856 -- 420 launch pairs of a
         // few dozen workgroups instead of 140)
         // (... of what the device has free: a smaller or fuller GPU takes smaller chunks instead of an allocation failure)
-        size_t mem_free = 0, mem_total = 0;
-        int64_t fant_budget = 2048ll << 20;
-        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) {
-            const int64_t have = (int64_t)(mem_free / 8) + (int64_t)(h->part_bgS[0].cap + h->part_bgS[1].cap + h->scratch.cap) / 2;
-            fant_budget = std::max<int64_t>(64ll << 20, std::min<int64_t>(fant_budget, have));
-        } else (void)hipGetLastError();
+        // (queried when the number of fantasies changes, not per pass: the chunk plan -- buffer sizes, launch counts -- then
+        // stays what it was from pass to pass and across ranks that share a device)
+        if (h->fant_budget_S != S) {
+            size_t mem_free = 0, mem_total = 0;
+            int64_t b = 2048ll << 20;
+            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) {
+                const int64_t have = (int64_t)(mem_free / 8) + (int64_t)(h->part_bgS[0].cap + h->part_bgS[1].cap + h->scratch.cap) / 2;
+                b = std::max<int64_t>(64ll << 20, std::min<int64_t>(b, have));
+            } else (void)hipGetLastError();
+            h->fant_budget = b;
+            h->fant_budget_S = S;
+        }
+        const int64_t fant_budget = h->fant_budget;
         int64_t cap = fant_budget / ((int64_t)nrb * 2 * S * 8) / SPX_BN * SPX_BN;
         if (cap < SPX_BN) cap = SPX_BN;
         if (Mc > cap) {
@@ -894,7 +911,7 @@ static int ei_run_impl(spx_handle* h, int32_t flags, bool factor_pending)
             TIMED_S(ST_COV_CROSS, Pi, launch_cov_cross(Pi, h->Xs.d() + (size_t)h0 * Np * Dp, h->s1.d() + (size_t)h0 * Np,
                                                       Cs + (size_t)h0 * mc * Dp, s2 + (size_t)h0 * mc,
                                                       h->htab.d() + (size_t)h0 * SPX_HT, h->Kst[k].d(), (int)N, Np, mc, Dp, nhb, dev_kind(h),
-                                                      cov_live_rows));
+                                                      cov_live_rows, h->cov_flat != 0));
             if (ns == 2) {
                 HIPCHK(hipEventRecord(h->ev_sync[k], P));
                 HIPCHK(hipStreamWaitEvent(G, h->ev_sync[k], 0));
@@ -1347,16 +1364,34 @@ int spx_get_stat(spx_handle* h, const char* name, int64_t* value)
 {
     if (!h || !name || !value) return fail(SPX_ERR_ARG, "spx_get_stat: null");
     if (h->multi) {
-        if (!strcmp(name, "ranks_seen")) return spx_multi_stat(h->multi, name, value);
+        if (!strcmp(name, "ranks_seen") || !strcmp(name, "flow_fallbacks") || !strcmp(name, "flow_rearms"))
+            return spx_multi_stat(h->multi, name, value);
         return fail(SPX_ERR_ARG, "spx_get_stat: ask the per-device handles (single-GPU handles only)");
     }
     if (!strcmp(name, "flow_fallbacks")) *value = h->flow_fallbacks;          // hand-off time-outs of k_lean_flow so far
     else if (!strcmp(name, "flow_enabled")) *value = (h->lean_flow != 0 && !h->flow_demoted);   // 0 while a time-out keeps the handle on one launch per block column
     else if (!strcmp(name, "flow_rearms")) *value = h->flow_rearms;           // times the handle went back to k_lean_flow after a fallback
-    else if (!strcmp(name, "ranks_seen")) *value = h->comm ? h->ranks_seen : 1;   // records in the table of the last all-gather (the ranks that took part)
+    else if (!strcmp(name, "ranks_seen")) *value = h->comm ? h->ranks_seen : 1;   // size of the communicator the last exchange ran on (its table has one record per rank)
     else if (!strcmp(name, "n_cu")) *value = h->n_cu;
     else if (!strcmp(name, "last_step_fused")) *value = h->last_fused ? 1 : 0; // the last EI pass ran k_ei_fused128
     else if (!strcmp(name, "last_step_skipped_padding")) *value = h->last_skip_pad ? 1 : 0;   // ... skipped the padding of N (k_predict_gemm_tail)
+    else if (!strcmp(name, "hip_runtime_version") || !strcmp(name, "hip_driver_version")) {
+        // what the process runs on: a measurement names it (bench.py's line), two boxes of one pool differed in round 5
+        int v = 0;
+        HIPCHK(name[4] == 'r' ? hipRuntimeGetVersion(&v) : hipDriverGetVersion(&v));
+        *value = v;
+    } else if (!strcmp(name, "clock_khz") || !strcmp(name, "mem_clock_khz") || !strcmp(name, "wall_clock_khz")
+               || !strcmp(name, "l2_bytes") || !strcmp(name, "mem_bus_bits")) {
+        int rc = ensure_init(h);
+        if (rc) return rc;
+        int v = 0;
+        const hipDeviceAttribute_t a = !strcmp(name, "clock_khz") ? hipDeviceAttributeClockRate
+            : !strcmp(name, "mem_clock_khz") ? hipDeviceAttributeMemoryClockRate
+            : !strcmp(name, "wall_clock_khz") ? hipDeviceAttributeWallClockRate
+            : !strcmp(name, "l2_bytes") ? hipDeviceAttributeL2CacheSize : hipDeviceAttributeMemoryBusWidth;
+        HIPCHK(hipDeviceGetAttribute(&v, a, h->device));
+        *value = v;
+    }
     else return fail(SPX_ERR_ARG, "spx_get_stat: unknown statistic '%s'", name);
     return SPX_OK;
 }

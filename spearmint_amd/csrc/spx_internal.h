@@ -113,6 +113,9 @@ struct spx_handle {
     int cov_kind = 0;                   // SPX_COVAR_* (option "covar"); SE = ARDSE kernels on unit length scales
     int lean_lazy = -1;                 // option "lean_lazy": 0 / 1 / -1 = by batch size
     int gemm_variant = 0;               // predict-GEMM variant of THIS handle (option "gemm_waves"); 0 = production
+    int64_t fant_budget = 0;            // bytes the per-fantasy partial means may take (an eighth of free memory, <= 2 GB) ...
+    int fant_budget_S = -1;             // ... as found when the number of fantasies last changed
+    int cov_flat = -1;                  // option "cov_flat": k_cov_flat for multi-round K(X*,X) launches 1 / 0 / -1 = default (on)
     int gemm_partial = -1;              // option "gemm_partial": skip the padding of N in the EI pass 1 / 0 / -1 = default (on)
     bool last_skip_pad = false;         // the last EI pass did
     struct spx_multi* multi = nullptr;  // non-null: this handle fronts several per-GPU handles (spx_multi.hip)

@@ -544,6 +544,13 @@ int spx_rccl_version(int32_t* version_code)
 
 int spx_create_multi(const int* device_ids, int32_t n_dev, spx_handle** out)
 {
+    return spx_create_multi_transport(device_ids, n_dev, SPX_TRANSPORT_NONE, out);
+}
+
+int spx_create_multi_transport(const int* device_ids, int32_t n_dev, int32_t transport, spx_handle** out)
+{
+    if (transport != SPX_TRANSPORT_NONE && transport != SPX_TRANSPORT_RCCL && transport != SPX_TRANSPORT_HOST)
+        return fail(SPX_ERR_ARG, "spx_create_multi_transport: transport must be SPX_TRANSPORT_NONE (by the device list), _RCCL or _HOST");
     if (!device_ids || !out || n_dev < 1 || n_dev > 64)
         return fail(SPX_ERR_ARG, "spx_create_multi: bad arguments (n_dev=%d)", n_dev);
     for (int i = 0; i < n_dev; ++i)
@@ -555,11 +562,11 @@ int spx_create_multi(const int* device_ids, int32_t n_dev, spx_handle** out)
     spx_multi* m = new spx_multi();
     m->n = n_dev;
     m->devs.assign(device_ids, device_ids + n_dev);
-    // SPX_MULTI_TRANSPORT=host: records through host memory even on distinct GPUs; =rccl: the RCCL code path even for
-    // repeated device ids (a real librccl refuses such a communicator; the thread-rendezvous stand-in of the tests,
-    // tests/c/fake_rccl.hip through SPX_RCCL_LIB, accepts it -- how a 1-GPU box runs the group section with n > 1)
-    const char* force = getenv("SPX_MULTI_TRANSPORT");
-    const bool want_host = force && !strcmp(force, "host"), want_rccl = force && !strcmp(force, "rccl");
+    // transport asked for explicitly (spx_create_multi_transport): HOST = records through host memory even on distinct
+    // GPUs; RCCL = the RCCL code path even for repeated device ids (a real librccl refuses such a communicator; the
+    // thread-rendezvous stand-in of the tests, tests/c/fake_rccl.hip through SPX_RCCL_LIB, accepts it -- how a 1-GPU box
+    // runs the group section with n > 1)
+    const bool want_host = transport == SPX_TRANSPORT_HOST, want_rccl = transport == SPX_TRANSPORT_RCCL;
     m->transport = ((distinct && !want_host) || want_rccl) ? SPX_TRANSPORT_RCCL : SPX_TRANSPORT_HOST;
     if (m->transport == SPX_TRANSPORT_RCCL) {
         int rc = load_rccl(&m->rccl);
@@ -671,7 +678,18 @@ int spx_multi_info(spx_multi* m, int32_t* n_dev, int32_t* transport, int32_t* de
 
 int spx_multi_stat(spx_multi* m, const char* name, int64_t* value)
 {
-    if (!strcmp(name, "ranks_seen")) { *value = m->n; return SPX_OK; }   // device slots whose records the exchange reduced
+    if (!strcmp(name, "ranks_seen")) { *value = m->n; return SPX_OK; }   // the device slots of the handle (= the size of its communicator)
+    if (!strcmp(name, "flow_fallbacks") || !strcmp(name, "flow_rearms")) {   // summed over the devices' handles
+        int64_t sum = 0;
+        for (spx_handle* k : m->kids) {
+            int64_t v = 0;
+            int rc = spx_get_stat(k, name, &v);
+            if (rc) return rc;
+            sum += v;
+        }
+        *value = sum;
+        return SPX_OK;
+    }
     return fail(SPX_ERR_ARG, "spx_get_stat: unknown statistic '%s' of a multi-device handle", name);
 }
 

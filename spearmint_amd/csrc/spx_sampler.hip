@@ -205,6 +205,7 @@ struct Evaluator {
     int D, max_rows;
     std::unordered_map<std::string, std::pair<double, bool> > memo[2];   // this batch's rows and the batch before
     int64_t calls = 0, rows = 0;
+    int64_t by_rows[34] = {0};   // calls by number of hyper rows (33: more than 32)
     int rc = 0;
 
     static std::string key_of(const double* r, int n) { return std::string((const char*)r, (size_t)n * 8); }
@@ -272,6 +273,7 @@ struct Evaluator {
         rc = fn(ctx, R.data(), n, lp.data());
         if (rc) throw SliceError{rc};
         calls += 1; rows += n;
+        by_rows[n > 32 ? 33 : n] += 1;
         memo[1].swap(memo[0]);
         memo[0].clear();
         for (auto& kv : index) memo[0][kv.first] = std::make_pair(lp[kv.second], (bool)(isinf(lp[kv.second]) && lp[kv.second] < 0));
@@ -518,6 +520,7 @@ int run_sampler(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rn
     double mean = hyper_io[0], noise = hyper_io[1], amp2 = hyper_io[2];
     Vec ls(hyper_io + 3, hyper_io + 3 + D);
     int64_t calls = 0, rows = 0, moves = 0, free_moves = 0, done = 0;
+    int64_t by_rows[34] = {0};
     int rc = SPX_OK;
     try {
         for (int it = 0; it < cfg->n_iter; ++it) {
@@ -539,8 +542,8 @@ int run_sampler(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rn
                 for (int i = 0; i < 3; ++i) dir[(size_t)i] = dir[(size_t)i] / nrm;
                 Uniforms u(&rng);
                 Vec x0 = {mean, amp2, noise};
-                struct Acc { int64_t &c, &r, &mv_, &f; Evaluator& e; Mover& m_; ~Acc() { c += e.calls; r += e.rows; mv_ += m_.moves; f += m_.free_moves; } }
-                    acc{calls, rows, moves, free_moves, ev, mv};
+                struct Acc { int64_t &c, &r, &mv_, &f; int64_t* hb; Evaluator& e; Mover& m_; ~Acc() { c += e.calls; r += e.rows; mv_ += m_.moves; f += m_.free_moves; for (int q = 0; q < 34; ++q) hb[q] += e.by_rows[q]; } }
+                    acc{calls, rows, moves, free_moves, by_rows, ev, mv};
                 Vec nx = mv.move(dir, x0, u, nullptr, 0, 0);
                 mean = nx[0]; amp2 = nx[1]; noise = cfg->noiseless ? 1e-3 : nx[2];
             }
@@ -558,8 +561,8 @@ int run_sampler(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rn
                 rng.shuffle(order);
                 Uniforms u(&rng);
                 Vec cur = ls;
-                struct Acc { int64_t &c, &r, &mv_, &f; Evaluator& e; Mover& m_; ~Acc() { c += e.calls; r += e.rows; mv_ += m_.moves; f += m_.free_moves; } }
-                    acc{calls, rows, moves, free_moves, ev, mv};
+                struct Acc { int64_t &c, &r, &mv_, &f; int64_t* hb; Evaluator& e; Mover& m_; ~Acc() { c += e.calls; r += e.rows; mv_ += m_.moves; f += m_.free_moves; for (int q = 0; q < 34; ++q) hb[q] += e.by_rows[q]; } }
+                    acc{calls, rows, moves, free_moves, by_rows, ev, mv};
                 for (int i = 0; i < D; ++i) {
                     Vec e((size_t)D, 0.0), e2;
                     e[(size_t)order[(size_t)i]] = 1.0;
@@ -584,7 +587,10 @@ int run_sampler(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rn
     rng.store(rng_io);
     hyper_io[0] = mean; hyper_io[1] = noise; hyper_io[2] = amp2;
     for (int i = 0; i < D; ++i) hyper_io[3 + i] = ls[(size_t)i];
-    if (stats_out) { stats_out[0] = calls; stats_out[1] = rows; stats_out[2] = moves; stats_out[3] = free_moves; stats_out[4] = done; }
+    if (stats_out) {
+        stats_out[0] = calls; stats_out[1] = rows; stats_out[2] = moves; stats_out[3] = free_moves; stats_out[4] = done;
+        for (int q = 0; q < 34; ++q) stats_out[5 + q] = by_rows[q];
+    }
     if (rc == SPX_ERR_NOT_PD) return fail(rc, "slice sampler: covariance not positive definite at a point the sampler evaluated");
     if (rc == SPX_ERR_SLICE_NAN) return fail(rc, "Slice sampler got a NaN");
     if (rc == SPX_ERR_SLICE_ZERO) return fail(rc, "Slice sampler shrank to zero!");

@@ -53,7 +53,7 @@ def exchange_records(local_value, local_index, device=None, group=None):
     """The one collective of the path: every rank contributes its 16-byte record {best mean EI
     (float64), global index (int64)} to ONE all-gather (P x 16 bytes; RCCL over xGMI with backend
     "nccl").  Returns the gathered table as a list of P (value, index) pairs in rank order -- the
-    same bytes on every rank; its length is the number of ranks that took part.  The record travels
+    same bytes on every rank; its length is the size of the group the collective ran on.  The record travels
     as raw bytes, so the index is exact over the whole int64 range.
 
     Without an initialised process group (single process) the table is this rank's own record."""

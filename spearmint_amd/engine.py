@@ -74,6 +74,7 @@ _vp = ctypes.c_void_p
 ABI = {
     "spx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "spx_create_multi": (ctypes.c_int, [_c_int32_p, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    "spx_create_multi_transport": (ctypes.c_int, [_c_int32_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_vp)]),
     "spx_multi_query": (ctypes.c_int, [_vp, _c_int32_p, _c_int32_p, _c_int32_p, ctypes.c_int32]),
     "spx_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "spx_rccl_version": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int32)]),
@@ -170,7 +171,7 @@ class SpxError(RuntimeError):
 
 def _sampler_result(lib, rc, rows, stats):
     st = {"calls": int(stats[0]), "rows": int(stats[1]), "moves": int(stats[2]), "free_moves": int(stats[3]),
-          "iterations": int(stats[4])}
+          "iterations": int(stats[4]), "calls_by_rows": [int(v) for v in stats[5:39]]}
     if rc == SPX_OK:
         return rows, st
     msg = lib.spx_last_error()
@@ -209,7 +210,7 @@ def sample_hypers_with(logprob_rows, cfg, hyper, hist, rng_state=None, lib=None)
             return SPX_ERR_ARG
     rng = RngState.from_numpy() if rng_state is None else rng_state
     rows = np.empty((int(cfg.n_iter), 3 + D))
-    stats = np.zeros(5, dtype=np.int64)
+    stats = np.zeros(39, dtype=np.int64)
     rc = lib.spx_sample_hypers_with(LOGPROB_FN(cb), None, ctypes.byref(cfg), ctypes.byref(rng), _dp(hyper), _dp(rows),
                                     _dp(hist), stats.ctypes.data_as(_c_int64_p))
     if rng_state is None:
@@ -233,7 +234,8 @@ class Engine(object):
         best, value, ei_mean, overall_ei = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
     """
 
-    def __init__(self, device=0, lib=None, devices=None):
+    def __init__(self, device=0, lib=None, devices=None, transport=None):
+        """transport (with devices=): None = by the device list, "rccl" / "host" = spx_create_multi_transport."""
         self._lib = load_library(lib)
         self._handle = _vp()
         # The handle, its HIP streams and device buffers belong to the process that created them.  The
@@ -247,7 +249,11 @@ class Engine(object):
             if not devs:
                 raise ValueError("Engine needs at least one device")
             arr = (ctypes.c_int32 * len(devs))(*devs)
-            self._check(self._lib.spx_create_multi(arr, len(devs), ctypes.byref(self._handle)))
+            if transport is None:
+                self._check(self._lib.spx_create_multi(arr, len(devs), ctypes.byref(self._handle)))
+            else:
+                code = {"rccl": 1, "host": 2}[transport]
+                self._check(self._lib.spx_create_multi_transport(arr, len(devs), code, ctypes.byref(self._handle)))
             self.devices = devs
             self.device = devs[0]
         else:
@@ -497,7 +503,7 @@ class Engine(object):
         import numpy.random as npr
         rng = RngState.from_numpy() if rng_state is None else rng_state
         rows = np.empty((int(cfg.n_iter), 3 + int(cfg.D)))
-        stats = np.zeros(5, dtype=np.int64)
+        stats = np.zeros(39, dtype=np.int64)
         rc = self._lib.spx_sample_hypers(self._h, ctypes.byref(cfg), ctypes.byref(rng), _dp(hyper), _dp(rows), _dp(hist),
                                          stats.ctypes.data_as(_c_int64_p))
         if rng_state is None:
@@ -607,5 +613,5 @@ class MultiEngine(Engine):
     RCCL all-gather all live inside libspx (csrc/spx_multi.hip); this class only keeps the
     round-1 constructor signature."""
 
-    def __init__(self, devices, lib=None):
-        Engine.__init__(self, lib=lib, devices=list(devices))
+    def __init__(self, devices, lib=None, transport=None):
+        Engine.__init__(self, lib=lib, devices=list(devices), transport=transport)

@@ -148,6 +148,27 @@ def test_engine_refuses_calls_from_a_forked_child(lib):
     eng.close()                            # idempotent
 
 
+def test_shipped_library_reads_only_the_documented_environment():
+    """no development knob is read from the environment inside the shipped library's launch path.  The only
+    SPX_* names libspx.so contains are the two deployment hooks include/spx.h documents (SPX_RCCL_LIB,
+    SPX_RCCL_ANY_VERSION); kernel / transport choices are handle options (spx_set_option: cov_flat, ...) or explicit
+    arguments (spx_create_multi_transport), and SPX_COV_RPW exists only in a `make DEV_KNOBS=1` build."""
+    import re
+    blob = open(engine.default_lib_path(), "rb").read()
+    names = set(m.decode() for m in re.findall(rb"SPX_[A-Z0-9_]{3,}(?=\x00)", blob))
+    env_like = set(n for n in names if not n.startswith(("SPX_ERR", "SPX_OK", "SPX_FLAG", "SPX_TRANSPORT", "SPX_COVAR")))
+    assert env_like == {"SPX_RCCL_LIB", "SPX_RCCL_ANY_VERSION"}, env_like
+    header = open(os.path.join(ROOT, "include", "spx.h")).read()
+    for n in env_like:
+        assert n in header
+    assert b"SPX_COV_" not in blob and b"SPX_MULTI_TRANSPORT" not in blob
+    # ... and the csrc sources call getenv for exactly these
+    src = "".join(open(os.path.join(ROOT, "spearmint_amd", "csrc", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "spearmint_amd", "csrc")) if f.endswith((".hip", ".h")))
+    shipped = re.sub(r"#ifdef SPX_DEV_KNOBS.*?#endif", "", src, flags=re.S)
+    assert set(re.findall(r'getenv\("(\w+)"\)', shipped)) == {"SPX_RCCL_LIB", "SPX_RCCL_ANY_VERSION"}
+
+
 def test_no_kernel_of_the_shipped_library_needs_scratch(tmp_path):
     """Every gfx950 kernel in libspx.so has private_segment_fixed_size 0 (no spills, no recursion, no dynamically
     indexed private arrays).  A kernel with a private segment makes the runtime allocate per-queue scratch behind every

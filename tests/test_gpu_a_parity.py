@@ -619,22 +619,16 @@ def test_two_stream_step_waits_for_the_pending_factorisation(eng):
 def test_flat_covariance_launch_is_bit_identical(eng, tmp_path, N):
     """K(X*,X) launches of several residency rounds run as k_cov_flat (equal contiguous shares of the
     launch for a whole multiple of the chip's places) -- the same arithmetic per element: EI of every (candidate, draw) equals,
-    bit for bit, the 3-D grid's (SPX_COV_FLAT=0, read once per process: a child process)."""
-    import subprocess
-    import sys
+    bit for bit, the 3-D grid's (handle option cov_flat = 0; an environment variable until round 6)."""
     comp, cand, vals, hypers = synthetic_problem(N, 20000, 9, 4, 79)
     a = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
     assert eng.stat("last_step_skipped_padding") == (1 if N == 900 else 0)
-    out = str(tmp_path / "grid3d.npz")
-    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
-            "from spearmint_amd.engine import Engine\n"
-            "from spearmint_amd.synthetic import synthetic_problem\n"
-            "comp, cand, vals, hypers = synthetic_problem(%d, 20000, 9, 4, 79)\n"
-            "r = Engine(0).ei_grid(comp, vals, cand, hypers, want_draws=True)\n"
-            "np.savez(%r, idx=r[0], val=r[1], draws=r[3])\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, out))
-    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, SPX_COV_FLAT="0"))
-    b = np.load(out)
-    assert int(b["idx"]) == a[0] and float(b["val"]) == a[1] and np.array_equal(b["draws"], a[3])
+    eng.set_option("cov_flat", 0)
+    try:
+        b = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+    finally:
+        eng.set_option("cov_flat", -1)
+    assert b[0] == a[0] and b[1] == a[1] and np.array_equal(b[3], a[3])
     ref = orc.ei_over_hypers(comp, cand[:3000], vals, hypers)         # ... and both equal the oracle
     assert_ei_close(a[3][:3000], ref)
 

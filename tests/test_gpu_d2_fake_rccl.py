@@ -4,7 +4,7 @@ The real librccl cannot form a communicator of several ranks on one device, so o
 the collectives -- ncclCommInitAll + the ncclGroup of P ncclAllGather calls of a multi-device handle, the record table
 for P > 1, the 2-D partition's ncclAllReduce, spx_comm_attach(nranks = P) -- never ran.  Here libspx binds
 tests/c/fake_rccl.hip instead (SPX_RCCL_LIB): a thread-rendezvous stand-in with the NCCL 2 signatures that moves the
-data on the callers' own streams, ordered by events as a collective orders them.  SPX_MULTI_TRANSPORT=rccl makes
+data on the callers' own streams, ordered by events as a collective orders them.  transport="rccl" (spx_create_multi_transport) makes
 spx_create_multi take the RCCL code path for repeated device ids.  Everything must equal the one-GPU handle: the
 winner, the per-candidate EI bits, the 2-D partition's all-reduced sums; a collective that fails must surface as
 SPX_ERR_HIP + spx_last_error (no hang, no crash).
@@ -44,7 +44,7 @@ def _child(fn, env, args, q):
 
 
 def _in_child(fn, *args, **env):
-    e = {"SPX_RCCL_LIB": _fake_lib(), "SPX_MULTI_TRANSPORT": "rccl"}
+    e = {"SPX_RCCL_LIB": _fake_lib()}
     e.update(env)
     ctx = multiprocessing.get_context("spawn")
     q = ctx.Queue()
@@ -77,7 +77,7 @@ def _multi_handle_case(P):
     one = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
     ops = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
     out = {"version": rccl_version()}
-    me = MultiEngine([0] * P)
+    me = MultiEngine([0] * P, transport="rccl")
     try:
         out["transport"] = me.transport()
         many = me.ei_grid(comp, vals, cand, hypers, want_draws=True)
@@ -144,7 +144,7 @@ def _partition_case(P, ph):
     from spearmint_amd.synthetic import synthetic_problem
     comp, cand, vals, hypers = synthetic_problem(150, 2111, 5, 7, 97)
     eng = Engine(0)
-    me = MultiEngine([0] * P)
+    me = MultiEngine([0] * P, transport="rccl")
     out = {}
     try:
         me.set_partition(ph)
@@ -254,12 +254,12 @@ def _failing_case(mode):
     out = {}
     if mode == "initall":
         try:
-            MultiEngine([0, 0])
+            MultiEngine([0, 0], transport="rccl")
             out["error"] = None
         except SpxError as e:
             out["error"] = str(e)
         return out
-    me = MultiEngine([0, 0, 0])
+    me = MultiEngine([0, 0, 0], transport="rccl")
     try:
         if mode == "allreduce":
             me.set_partition(3)
