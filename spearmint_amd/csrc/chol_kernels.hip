@@ -417,16 +417,19 @@ __device__ __forceinline__ void diag_block(double* S, double* XT, double* T16, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) dk_store<PUB>(Dk + (48 + g + 4 * r) * NB + 48 + li, Tp[(g + 4 * r) * 18 + li]);
     }
+    // the log-likelihood path only needs the diagonal of L_kk (diag_out; S is complete since the last barrier).  PUB: it
+    // leaves written through and drained (inv_finish below) BEFORE the block's last flag, so that a workgroup of the same
+    // launch that has seen the flag -- the one that reduces the log-likelihood, k_lean_flow's `fused` form -- reads it
+    if (PUB && diag_out && wave == 3) dk_store<true>(diag_out + lane, S[lane * LDP + lane]);
     if (wave > 0 && wave < 4) inv_finish<PUB>(t4, XT, T16, Dk, 3, wave - 1, g, li);
-    if (PUB) {   // the last block row (inv_finish drained this wave's stores)
-        if (wave > 0 && wave < 4 && lane == 0 && __hip_atomic_fetch_add(s_pub + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2)
+    if (PUB) {   // the last block row (inv_finish drained this wave's stores).  Wave 0 joins the count behind its not-PD
+                 // report above (its atomicCAS has returned): whoever sees the flag sees info too
+        if (lane == 0 && __hip_atomic_fetch_add(s_pub + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3)
             __hip_atomic_store(flag, flag_base + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     }
     STAMP(17);
-    // L_kk (upper part zero), 16 bytes per lane (S is complete since the last barrier); the log-likelihood path
-    // only needs its diagonal (diag_out)
-    if (diag_out && threadIdx.x < NB) diag_out[threadIdx.x] = S[threadIdx.x * LDP + threadIdx.x];
+    if (!PUB && diag_out && threadIdx.x < NB) diag_out[threadIdx.x] = S[threadIdx.x * LDP + threadIdx.x];
     if (Lkk) {
         for (int idx = threadIdx.x; idx < NB * NB / 2; idx += blockDim.x) {
             const int row = idx >> 5, col = (idx & 31) * 2;
@@ -1082,6 +1085,12 @@ __device__ __forceinline__ void flow_step(double* A, double* B, const double* pi
 struct FlowCov {
     const double* Xs; const double* X2s; const double* s1; const double* htab;   // null Xs: the tiles are in memory (k_cov ran)
     int N, Dp, kind;
+    // `fused` (comp != null; the log-likelihood call as ONE launch, round 6): x / ls, the row norms and the right-hand-side
+    // rows are formed where they are consumed -- no prologue launch -- and the last right-hand-side item of a draw reduces
+    // -sum log diag L - 0.5 |y|^2 into pinned host memory -- no reduction launch
+    const double* comp; const double* hyp; const double* vals;   // observations [N][D], raw hyper rows [nh][hs], values [N]
+    int D, hs;
+    double* lp_out; int* info_out;
 };
 
 template <int KIND>
@@ -1138,6 +1147,142 @@ __device__ __forceinline__ void flow_cov_tile_kind(const double* __restrict__ Xh
     }
 }
 
+// fused form: block b of the observations scaled by the draw's length scales, in LDS -- dst[r][c] = factor * x[64 b + r][c]
+// / ls[c] ([64][LDP], columns D .. Dp-1 and rows >= N zero) and nrm[r] = sum_c (x / ls)^2, value for value what
+// k_scale_rows writes to Xs / X2s / s1 (true division, the norm accumulated left to right by one thread per row)
+__device__ __forceinline__ void flow_scale_block(const FlowCov& cv, const double* __restrict__ lsh, int b, double* dst,
+                                                 double* nrm, double factor)
+{
+#pragma clang fp contract(off)
+    const int D = cv.D, Dp = cv.Dp, N = cv.N;
+    for (int e = threadIdx.x; e < NB * Dp; e += 256) {
+        const int r = e / Dp, c = e - r * Dp;
+        const int row = NB * b + r;
+        dst[r * LDP + c] = (row < N && c < D) ? cv.comp[(size_t)row * D + c] / lsh[c] : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        double acc = 0.0;
+        double* d = dst + threadIdx.x * LDP;
+        for (int c = 0; c < D; ++c) {
+            const double v = d[c];
+            acc = acc + v * v;
+            d[c] = factor * v;
+        }
+        nrm[threadIdx.x] = acc;
+    }
+    __syncthreads();
+}
+
+// flow_cov_tile_kind with both operands in LDS (Ar: rows of block I scaled, Bc: rows of block J scaled and doubled; nr / nc
+// their norms): the same contraction order, the same epilogue -- the same bits
+template <int KIND>
+__device__ __forceinline__ void flow_cov_tile_lds(const double* Ar, const double* Bc, const double* nr, const double* nc,
+                                                  double amp2, double noise, int N, int Dp, int I, int J, d4 (&acc)[4])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int j0 = NB * I + 16 * wave, c0 = NB * J, Q = Dp >> 2;
+    double s2v[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        s2v[nt] = nc[16 * nt + li];
+        acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    const double* pa = Ar + (16 * wave + li) * LDP + g * Q;
+    const double* pb = Bc + li * LDP + g * Q;
+    for (int q0 = 0; q0 < Q; q0 += 8) {
+        double af[8], bf[4][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q0 + q < Q) {
+                af[q] = pa[q0 + q];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bf[nt][q] = pb[16 * nt * LDP + q0 + q];
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q0 + q < Q) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = MFMA_F64(af[q], bf[nt][q], acc[nt]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + g + 4 * r;
+        const double s1v = nr[16 * wave + g + 4 * r];
+        double gv[4], cv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) gv[nt] = acc[nt][r];
+        corr_of_kind<KIND, 4>(gv, s1v, s2v, cv);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma clang fp contract(off)
+            const int c = c0 + 16 * nt + li;
+            const double eye = (j == c) ? 1.0 : 0.0;
+            double v = amp2 * (cv[nt] + 1e-6 * eye) + noise * eye;
+            if (j >= N || c >= N) v = eye;
+            acc[nt][r] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void flow_cov_tile_fused(const FlowCov& cv, int h, const double* Ar, const double* Bc, const double* nr,
+                                                    const double* nc, int I, int J, d4 (&acc)[4])
+{
+    const double noise = cv.htab[h * SPX_HT + 1], amp2 = cv.htab[h * SPX_HT + 2];
+    if (cv.kind == SPX_COV_MATERN32) flow_cov_tile_lds<SPX_COV_MATERN32>(Ar, Bc, nr, nc, amp2, noise, cv.N, cv.Dp, I, J, acc);
+    else if (cv.kind == SPX_COV_ARDSE) flow_cov_tile_lds<SPX_COV_ARDSE>(Ar, Bc, nr, nc, amp2, noise, cv.N, cv.Dp, I, J, acc);
+    else flow_cov_tile_lds<SPX_COV_MATERN52>(Ar, Bc, nr, nc, amp2, noise, cv.N, cv.Dp, I, J, acc);
+}
+
+// fused form: tile J of the right-hand-side block row -- row 0 = vals - mean (0 for pad entries), rows 1 .. 63 zero --
+// in the accumulator layout (k_lean_rhs_init's values)
+__device__ __forceinline__ void flow_rhs_tile(const FlowCov& cv, int h, int J, d4 (&acc)[4])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const double mean = cv.htab[h * SPX_HT + 0];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = J * NB + 16 * nt + li;
+        acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (wave == 0 && g == 0 && col < cv.N) acc[nt][0] = cv.vals[col] - mean;
+    }
+}
+
+// fused form, the last right-hand-side item of draw h (every diagonal block and every other right-hand-side tile of the draw
+// is published: it has waited for all of them): lp = -sum log diag(L) - 0.5 |y|^2 in k_lean_logprob's summation order, or
+// -inf if not positive definite, into pinned host memory -- and the draw's not-PD flag goes back to zero for the next call
+__device__ __forceinline__ void flow_logprob(const FlowCov& cv, int h, int Np, const double* __restrict__ diagL,
+                                             const double* __restrict__ rhs_h, int* info_h, double* red)
+{
+    double sl = 0.0, sq = 0.0;
+    for (int i = threadIdx.x; i < cv.N; i += 256) {
+        sl += log(__hip_atomic_load(diagL + (size_t)h * Np + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const double gi = __hip_atomic_load(rhs_h + (size_t)(i >> 6) * LEAN_TILE + ((((i & 63) >> 4) * 2) * 256 + (i & 15)) * 2,
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sq += gi * gi;
+    }
+    red[threadIdx.x] = sl;
+    red[256 + threadIdx.x] = sq;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[threadIdx.x] += red[threadIdx.x + s];
+            red[256 + threadIdx.x] += red[256 + threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int bad = __hip_atomic_load(info_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cv.lp_out[h] = bad ? -__builtin_inf() : (-red[0] - 0.5 * red[256]);
+        // (the flag is what the host polls -- option lean_poll: it leaves behind the value, at system scope)
+        __hip_atomic_store(cv.info_out + h, bad, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(info_h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __device__ __forceinline__ void flow_cov_tile(const FlowCov& cv, int h, int Np, int I, int J, d4 (&acc)[4])
 {
     const double* Xh = cv.Xs + (size_t)h * Np * cv.Dp;
@@ -1154,7 +1299,7 @@ template <bool DIAG>
 __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, double* __restrict__ row, double* __restrict__ Lh,
                                            double* __restrict__ Dh, const int* lf, int* lf_row, int* df, int* info_h,
                                            double* __restrict__ diag_out, int i, int lo, int hi, int nblk, int gen,
-                                           const FlowCov& cov, int h, bool is_rhs, int* busy)
+                                           const FlowCov& cov, int h, bool is_rhs, int* busy, const double* lp_diag = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -1167,7 +1312,22 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
 #endif
     if (DIAG) FSTAMP(h, i, 0);
     if (!DIAG) { flow_yield(busy); __syncthreads(); }
-    if (cov.Xs && !is_rhs) {
+    if (cov.comp && !is_rhs) {
+        // fused: the operands of the two Gram tiles in LDS (A: rows of block i; B: doubled rows of block lo, then of block hi)
+        const double* lsh = cov.hyp + (size_t)h * cov.hs + 3;
+        flow_scale_block(cov, lsh, i, A, T16, 1.0);
+        if (two) {
+            flow_scale_block(cov, lsh, lo, B, T16 + NB, 2.0);
+            flow_cov_tile_fused(cov, h, A, B, T16, T16 + NB, i, lo, a0);
+            __syncthreads();
+        }
+        flow_scale_block(cov, lsh, hi, B, T16 + NB, 2.0);
+        flow_cov_tile_fused(cov, h, A, B, T16, T16 + NB, i, hi, a1);
+        __syncthreads();                                                     // A, B and T16 are free again
+    } else if (cov.comp) {
+        if (two) flow_rhs_tile(cov, h, lo, a0);
+        flow_rhs_tile(cov, h, hi, a1);
+    } else if (cov.Xs && !is_rhs) {
         if (two) flow_cov_tile(cov, h, nblk * NB, i, lo, a0);
         flow_cov_tile(cov, h, nblk * NB, i, hi, a1);
     } else {
@@ -1266,6 +1426,8 @@ __device__ __forceinline__ void flow_chunk(double* A, double* B, double* T16, do
         drain_stores();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(lf_row + hi, 8 * gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // fused: the right-hand-side item of the last column pair is the last link of the draw -- it reduces the log-likelihood
+        if (is_rhs && cov.lp_out && hi == nblk - 1) flow_logprob(cov, h, nblk * NB, lp_diag, row, info_h, A);
     }
 }
 
@@ -1328,7 +1490,7 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
     // the two kinds of chunk as two straight-line bodies (one body with the distinction inside costs the register
     // allocator 110 registers more than either)
     if (diag) flow_chunk<true>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, diagL ? diagL + (size_t)h * Np + (size_t)i * NB : nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs, busy);
-    else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs, busy);
+    else flow_chunk<false>(A, B, T16, row, Lh, Dh, lf, lf_row, df, info_h, nullptr, i, lo, hi, nblk, gen, cov, h, is_rhs, busy, diagL);
     if (threadIdx.x == 0 && atomicAdd(tickets + 1, 1u) == gridDim.x - 1) {   // everybody else has left (and long since drawn a ticket)
         __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1338,9 +1500,13 @@ __global__ __launch_bounds__(256, 2) void k_lean_flow(double* __restrict__ Lt, d
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
                       int* dflags, unsigned* tickets, int Np, int nh, int gen, bool alone,
                       const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind,
-                      int* cu_busy, int spin_limit)
+                      int* cu_busy, int spin_limit, const FlowFused* fused)
 {
-    FlowCov cov{Xs, X2s, s1, htab, N, Dp, kind};
+    FlowCov cov{Xs, X2s, s1, htab, N, Dp, kind, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
+    if (fused) {
+        cov.comp = fused->comp; cov.hyp = fused->hyp; cov.vals = fused->vals; cov.D = fused->D; cov.hs = fused->hs;
+        cov.lp_out = fused->lp_out; cov.info_out = fused->info_out;
+    }
     const int nblk = Np / NB;
     int ny = rhs ? (nblk + 1) / 2 : 0;                         // the right-hand-side rows (the EI path has none)
     for (int i = 0; i < nblk; ++i) ny += (i + 2) / 2;

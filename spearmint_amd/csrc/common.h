@@ -72,10 +72,15 @@ void launch_lean_step(hipStream_t s, double* Lt, double* Dinv, int* info, double
 void launch_lean_trsm(hipStream_t s, double* Lt, const double* Dinv, double* rhs, int Np, int k, int nh);
 void launch_lean_step_ps(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* flags,
                          int Np, int k, int nh);
+// (k_lean_flow's `fused` form -- the log-likelihood call as one launch: where the raw inputs and the pinned outputs are)
+struct FlowFused {
+    const double* comp; const double* hyp; const double* vals; int D, hs;
+    double* lp_out; int* info_out;
+};
 void launch_lean_flow(hipStream_t s, double* Lt, double* Dinv, int* info, double* rhs, double* diagL, int* lflags,
                       int* dflags, unsigned* tickets, int Np, int nh, int gen, bool alone,
                       const double* Xs, const double* X2s, const double* s1, const double* htab, int N, int Dp, int kind,
-                      int* cu_busy, int spin_limit = 0);
+                      int* cu_busy, int spin_limit = 0, const FlowFused* fused = nullptr);
 void launch_lean_rhs_init(hipStream_t s, const double* vals, const double* htab, double* rhs, int N, int Np, int nh,
                           int* info, int* flags);
 void launch_lean_logprob(hipStream_t s, const double* diagL, const double* rhs, const int* info, double* out, int* info_out,

@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+
 #include "spx_internal.h"
 #include "np_sum.h"
 
@@ -252,6 +254,12 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
         h->lean_merge = value < 0 ? -1 : (value != 0);
         return SPX_OK;
     }
+    if (!strcmp(name, "lean_one")) {       // spx_gp_logprob as one launch (1, default) or prologue + k_lean_flow + reduction (0): same bits
+        h->lean_one = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
+    if (!strcmp(name, "lean_poll")) { h->lean_poll = value < 0 ? -1 : (value != 0); return SPX_OK; }   // (spx_internal.h)
+    if (!strcmp(name, "lean_zc")) { h->lean_zc = value < 0 ? -1 : (value != 0); return SPX_OK; }
     if (!strcmp(name, "cov_flat")) {       // K(X*,X) launches of several residency rounds: equal contiguous shares (k_cov_flat; 1, default) or the 3-D grid (0)
         h->cov_flat = value < 0 ? -1 : (value != 0);
         return SPX_OK;
@@ -434,7 +442,18 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // every entry point that queues work on it synchronises before it returns, so the staging buffer is free)
     if ((rc = h->pin_up.reserve(raw.size() * 8))) return rc;
     memcpy(h->pin_up.p, raw.data(), raw.size() * 8);
-    HIPCHK(hipMemcpyAsync(h->hyp.p, h->pin_up.p, raw.size() * 8, hipMemcpyHostToDevice, s));
+    // (the fused log-likelihood launch reads the rows out of the pinned buffer itself -- option lean_zc: one stream operation
+    // fewer in front of it; decided below, where `fused` is known: the copy is queued unless that form runs)
+    // (measured, profiles/r06_lean_one_ab.log: one launch instead of three is -11 us of 46 at N <= 64 with the polled
+    // completion and the zero-copy rows, -12 of 91 at N = 256, -2 ... -4 % up to N = 1024; at N = 2048 with several draws the
+    // items' own scaling costs more than the two launches did (+3 %), and with hundreds of items the reads of host memory do)
+    const bool fused_early = lean && nh <= 32 && h->lean_merge != 0 && h->lean_flow != 0 && !h->flow_demoted && h->lean_flow_cov != 0
+                             && h->lean_one != 0 && h->fused_lp != nullptr && Dp <= 64
+                             && (h->lean_one > 0 || nblk <= 16 || nh <= 2);
+    int fused_items = (nblk + 1) / 2;
+    for (int i = 0; i < nblk; ++i) fused_items += (i + 2) / 2;
+    const bool zero_copy = fused_early && h->lean_zc != 0 && !h->timing && (h->lean_zc > 0 || (int64_t)nh * fused_items <= 256);
+    if (!zero_copy) HIPCHK(hipMemcpyAsync(h->hyp.p, h->pin_up.p, raw.size() * 8, hipMemcpyHostToDevice, s));
     if (h->timing || !lean) HIPCHK(hipEventRecord(t0, s));
     // the log-likelihood path zeroes info (and the hand-off flags) in its right-hand-side kernel: two stream operations
     // fewer per call
@@ -447,6 +466,16 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // them needs x / ls (k_lean_flow builds K(X,X) itself: the default), the scaling of the observations and the
     // right-hand-side rows are ONE launch, further down where the right-hand side used to be written (option lean_merge).
     const bool merged_prologue = lean && nh <= 32 && h->lean_merge != 0 && h->lean_flow != 0 && !h->flow_demoted && h->lean_flow_cov != 0;
+    // ... and since round 6 NO launch of their own (option lean_one): k_lean_flow's items scale the rows they need into LDS,
+    // generate the right-hand-side rows, and the last item of a draw reduces the log-likelihood into pinned host memory --
+    // the call is the upload of the hyper rows and ONE launch.  (Dp <= 64: a block's scaled rows fit the kernel's LDS tile.)
+    const bool fused = fused_early;
+    h->fused_ran = fused;
+    if (fused && h->info_clean_ptr != h->info.p) {     // the not-PD flags: zero once; the fused launch leaves them zero
+        HIPCHK(hipMemsetAsync(h->info.p, 0, h->info.cap, s));
+        h->info_clean_ptr = h->info.p;
+    }
+    if (!fused) h->info_clean_ptr = nullptr;
     // x / ls and, in the same launch, the second operand pre-multiplied by 2 (gp.py:50; exact)
     if (!merged_prologue)
         TIMED(ST_SCALE, launch_scale_rows(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, 1.0, h->Xs.d(), h->s1.d(), h->X2s.d(),
@@ -522,7 +551,8 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         rhs = h->rhs.d();
         if (rl) {
             if ((rc = h->diagL.reserve((size_t)nh * Np * 8))) return rc;
-            if (merged_prologue)     // (implies flow and cov_in_flow: nothing before this point read x / ls)
+            if (fused) {}            // (nothing to launch)
+            else if (merged_prologue)     // (implies flow and cov_in_flow: nothing before this point read x / ls)
                 TIMED(ST_SCALE, launch_lean_prologue(s, h->comp.d(), N, Np, D, Dp, ls, hs, nh, h->Xs.d(), h->s1.d(), h->X2s.d(),
                                                      h->vals.d(), h->htab.d(), rhs, (int*)h->info.p, ps ? (int*)h->ps_flags.p : nullptr));
             else
@@ -534,10 +564,12 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
         h->lean_tiled = rl != 0;
     }
     h->factor_tiled = !lean && flow;
+    FlowFused ff{h->comp.d(), zero_copy ? (const double*)h->pin_up.p : h->hyp.d(), h->vals.d(), D, hs, h->fused_lp, h->fused_info};
+    const double* htab_dev = zero_copy ? (const double*)h->pin_up.p + (size_t)nh * hs : h->htab.d();
     if (flow)
         TIMED(ST_CHOL_DIAG, launch_lean_flow(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, lean ? h->diagL.d() : nullptr, lflags, dflags, tickets, Np, nh, h->flow_gen, flow_alone,
-                                             cov_in_flow ? h->Xs.d() : nullptr, h->X2s.d(), h->s1.d(), h->htab.d(), (int)N, Dp, dev_kind(h),
-                                             h->lean_flow_yield != 0 ? cu_busy : nullptr, h->flow_spin_limit));
+                                             cov_in_flow ? h->Xs.d() : nullptr, h->X2s.d(), h->s1.d(), htab_dev, (int)N, Dp, dev_kind(h),
+                                             h->lean_flow_yield != 0 ? cu_busy : nullptr, h->flow_spin_limit, fused ? &ff : nullptr));
     for (int k = 0; k < (flow ? 0 : nblk); ++k) {
         if (ps) {
             TIMED(ST_CHOL_DIAG, launch_lean_step_ps(s, h->Lm.d(), h->Dinv.d(), (int*)h->info.p, rhs, h->diagL.d(), (int*)h->ps_flags.p, Np, k, nh));
@@ -1189,20 +1221,45 @@ int spx_gp_logprob(spx_handle* h, double* out)
     return rc;
 }
 
+#define SPX_POLL_SENTINEL 0x7fffffff   // no not-PD flag has this value (pivots <= 2^20, time-outs < 0)
 static int gp_logprob_once(spx_handle* h, double* out)
 {
-    int rc = do_factor(h, true, true, true);   // K(X,X), Cholesky, forward solve -- no inverse; queued, not yet synchronised
+    // the kernels write the H values and the H not-PD flags straight into pinned host memory: no device-to-host copies
+    // (two of them, to pageable memory, were 40 us of a 95 us call at N = 64)
+    int rc;
+    if ((rc = ensure_init(h))) return rc;
+    if ((rc = h->pin_res.reserve((size_t)h->H * 12))) return rc;
+    double* lp_host = (double*)h->pin_res.p;
+    int* info_host = (int*)(lp_host + h->H);
+    h->fused_lp = lp_host; h->fused_info = info_host;
+    const bool polled = h->lean_poll != 0 && !h->timing;
+    if (polled) for (int k = 0; k < h->H; ++k) info_host[k] = SPX_POLL_SENTINEL;   // (coherent pinned memory: in place before the launch is queued)
+    rc = do_factor(h, true, true, true);   // K(X,X), Cholesky, forward solve -- no inverse; queued, not yet synchronised
+    h->fused_lp = nullptr; h->fused_info = nullptr;
     if (rc) return rc;
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
     std::vector<int> info(h->H);
     if (h->lean_tiled) {
-        // the kernel writes the H values and the H not-PD flags straight into pinned host memory: no device-to-host copies
-        // (two of them, to pageable memory, were 40 us of a 95 us call at N = 64)
-        if ((rc = h->pin_res.reserve((size_t)h->H * 12))) return rc;
-        double* lp_host = (double*)h->pin_res.p;
-        int* info_host = (int*)(lp_host + h->H);
-        launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, lp_host, info_host, (int)h->N, h->lean_np, h->H);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!h->fused_ran)   // (the fused launch has reduced the log-likelihood itself)
+            launch_lean_logprob(h->stream, h->diagL.d(), h->rhs.d(), (const int*)h->info.p, lp_host, info_host, (int)h->N, h->lean_np, h->H);
+        // The fused launch stores every draw's value, then -- released at system scope -- its flag into the pinned buffer: the
+        // host watches the flags instead of waiting for the stream to drain (the end-of-kernel release and the completion
+        // signal are ~7 us of a 42 us call).  What is still running then -- other workgroups' last instructions, the ticket
+        // reset -- is ordered in front of whatever this stream is given next.  Bounded: after 20 ms (a long call at N = 8192
+        // takes 10) the stream is synchronised the ordinary way.
+        bool seen = false;
+        if (h->fused_ran && polled) {
+            volatile int* fl = (volatile int*)info_host;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spin = 0;; ++spin) {
+                int k = 0;
+                while (k < h->H && __atomic_load_n(&fl[k], __ATOMIC_ACQUIRE) != SPX_POLL_SENTINEL) ++k;
+                if (k == h->H) { seen = true; break; }
+                if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            }
+        }
+        if (!seen) HIPCHK(hipStreamSynchronize(h->stream));
+        else LAUNCHCHK();
         memcpy(out, lp_host, (size_t)h->H * 8);
         memcpy(info.data(), info_host, (size_t)h->H * sizeof(int));
     } else {

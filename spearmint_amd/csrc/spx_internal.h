@@ -115,6 +115,16 @@ struct spx_handle {
     int gemm_variant = 0;               // predict-GEMM variant of THIS handle (option "gemm_waves"); 0 = production
     int64_t fant_budget = 0;            // bytes the per-fantasy partial means may take (an eighth of free memory, <= 2 GB) ...
     int fant_budget_S = -1;             // ... as found when the number of fantasies last changed
+    int lean_one = -1;                  // option "lean_one": the log-likelihood call as ONE launch (scaling, right-hand side and the
+                                        // reduction inside k_lean_flow) 1 / 0 / -1 = default (on)
+    int lean_poll = -1;                 // option "lean_poll": the fused call's results are awaited by polling their pinned flags
+                                        // (1, default) instead of hipStreamSynchronize (0)
+    int lean_zc = -1;                   // option "lean_zc": the fused launch reads the hyper rows from the pinned staging buffer
+                                        // itself (1, default) instead of behind a host-to-device copy (0)
+    double* fused_lp = nullptr;         // (spx_gp_logprob -> do_factor: pinned destinations of the fused form's results)
+    int* fused_info = nullptr;
+    bool fused_ran = false;             // the last do_factor took the fused form
+    const void* info_clean_ptr = nullptr;   // the not-PD flags at this address are all zero (left so by the fused launch)
     int cov_flat = -1;                  // option "cov_flat": k_cov_flat for multi-round K(X*,X) launches 1 / 0 / -1 = default (on)
     int gemm_partial = -1;              // option "gemm_partial": skip the padding of N in the EI pass 1 / 0 / -1 = default (on)
     bool last_skip_pad = false;         // the last EI pass did

@@ -718,6 +718,52 @@ def test_merged_loglikelihood_prologue_is_bit_identical(eng, N, D, H):
     assert np.allclose(out[1][0][ok], ref[ok], rtol=1e-9, atol=1e-9 * N)
 
 
+@pytest.mark.parametrize("N,D,H,covar", [(2, 1, 1, "Matern52"), (5, 2, 3, "Matern52"), (20, 2, 7, "Matern52"), (64, 3, 6, "Matern52"),
+                                         (65, 8, 3, "Matern52"), (128, 8, 32, "Matern52"), (200, 5, 12, "Matern32"), (256, 8, 22, "Matern52"),
+                                         (500, 17, 5, "ARDSE"), (700, 33, 6, "Matern52"), (1024, 16, 8, "Matern52"),
+                                         (2048, 32, 4, "Matern52"), (300, 4, 40, "Matern52"), (130, 100, 3, "Matern52"), (90, 6, 4, "SE")])
+def test_fused_loglikelihood_call_is_bit_identical(N, D, H, covar):
+    """Round 6: spx_gp_logprob as ONE launch (option lean_one, default on) -- k_lean_flow's items scale
+    the observation rows they need into LDS, generate the right-hand-side rows, and the last item of each draw reduces
+    -sum log diag L - 0.5 |y|^2 into pinned host memory; no prologue launch, no reduction launch.  Same values bit for bit
+    as the three-launch form (lean_one = 0): with a not-PD draw in the batch, after a call with other sizes, called
+    repeatedly (the not-PD flags are left clean by the launch itself), for every covariance function, beyond 32 draws and
+    for D > 64 (where the call keeps the three-launch form) -- and equal to the oracle."""
+    from spearmint_amd.engine import Engine
+    eng = Engine(0)
+    try:
+        eng.set_covar(covar)
+        comp, cand, vals, hypers = synthetic_problem(N, 16, D, H, 5400 + N)
+        if H >= 3:
+            hypers[H // 2, 2] = -1.0                       # one draw that is not positive definite
+        other = synthetic_problem(N + 37, 16, D, max(1, H - 1), 11)
+        out = []
+        for on in (0, 1):
+            eng.set_option("lean_one", on)
+            eng.set_observations(other[0], other[2]); eng.set_hypers(other[3]); eng.gp_logprob()
+            eng.set_observations(comp, vals); eng.set_hypers(hypers)
+            first = (eng.gp_logprob(), eng.not_pd_info())
+            for _ in range(3):                             # ... and again: nothing stale
+                eng.set_hypers(hypers)
+                again = (eng.gp_logprob(), eng.not_pd_info())
+                assert np.array_equal(again[0], first[0]) and again[1] == first[1]
+            good = np.delete(hypers, H // 2, axis=0) if H >= 3 else hypers
+            eng.set_hypers(good)                           # the failed draw's flag does not leak into the next call
+            clean = eng.gp_logprob()
+            assert np.isfinite(clean).all() and eng.not_pd_info()[0] < 0
+            out.append((first, clean))
+        assert np.array_equal(out[0][0][0], out[1][0][0]) and out[0][0][1] == out[1][0][1]
+        assert np.array_equal(out[0][1], out[1][1])
+        if covar == "Matern52":
+            ref = np.array([orc.gp_logprob(comp, vals, hypers[h, 0], hypers[h, 2], hypers[h, 1], hypers[h, 3:]) if hypers[h, 2] > 0 else -np.inf
+                            for h in range(H)])
+            ok = np.isfinite(ref)
+            assert np.array_equal(np.isneginf(out[1][0][0]), ~ok)
+            assert np.allclose(out[1][0][0][ok], ref[ok], rtol=1e-9, atol=1e-9 * N)
+    finally:
+        eng.close()
+
+
 def test_step_argument_errors_leave_nothing_queued(eng):
     """spx_ei_step checks its flags BEFORE it queues the factorisation, and any later error exit of a pending
     step returns with the streams idle and without an unchecked factor."""
