@@ -284,7 +284,7 @@ def platform_info(eng, device):
     return info
 
 
-def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3):
+def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3, with_reference=True):
     """The cpu_baseline leg END TO END: one whole `GPEIOptChooser.next()` -- slice sampling of the
     hyper-parameters (burn-in + mcmc_iters draws), both EI passes over the grid, the L-BFGS-B refinement of the best 20
     candidates -- by the reference's OWN chooser (S/chooser/GPEIOptChooser.py:217-328, lib2to3-converted, numpy/scipy on this
@@ -295,7 +295,7 @@ def next_baseline(N=256, M=20000, D=8, mcmc_iters=10, burnin=10, seed=3):
     import numpy.random as npr
     from oracle import ref_py3
     from spearmint_amd.chooser import GPEIOptChooser as ours_mod
-    mods = ref_py3.load() if ref_py3.available() else ref_py3.load_shipped()
+    mods = (ref_py3.load() if ref_py3.available() else ref_py3.load_shipped()) if with_reference else None
     comp, cand, vals, _ = synthetic_problem(N, M, D, 1, 9)
     grid = np.vstack((comp, cand))
     values = np.concatenate((vals, np.full(M, np.nan)))
@@ -1000,6 +1000,19 @@ def main():
                     "collective": ("libspx ncclAllReduce(SUM) of %d doubles on the handle's stream (spx_set_partition)"
                                    if use_lib else "host-side sums + torch all-reduce(SUM) of %d doubles") % cfg["M"],
                     "ms_per_step": dt2 / esteps * 1e3, "best_index": int(r2[0]), "best_ei": float(r2[1])}
+
+    # ---- the caller of the hot path end to end, at Spearmint's operating size (`bench.py --next-baseline` adds
+    # the reference's own next() beside it): one warm GPEIOptChooser.next() -- native sampler (spx_sample_hypers), two EI passes,
+    # lock-step refinement -- and the round-5 form of the same call on this box
+    if world == 1 and rank == 0 and not args.skip_extras and engine_name == "libspx":
+        try:
+            nb = next_baseline(with_reference=False)
+            out["next_call"] = {"what": nb["what"], "config": nb["config"], "warm_s": nb["ours"]["warm_s"], "cold_s": nb["ours"]["cold_s"],
+                                "round5_form_warm_s": nb["ours"]["round5_form_warm_s"], "sampler_stats": nb["ours"]["sampler_stats"],
+                                "speculation_depth": nb["ours"]["speculation_depth"], "proposal": nb["ours"]["proposal"],
+                                "repeatable": nb["ours_repeatable"], "round5_form_same_proposal": nb["ours"]["round5_form_same_proposal"]}
+        except Exception as ex:
+            out["next_call"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if not args.skip_extras:
         esteps = max(args.extra_steps, 5) if world > 1 else args.extra_steps

@@ -657,7 +657,9 @@ int predict_gemm_padding_plan(int variant, int N, int Np)
 }
 
 // Variants (spx_set_option "gemm_waves", per handle): 0 / 32 = production (k_predict_gemm_tri: 4 waves, LDS-DMA
-// staging, zero tiles of the diagonal block skipped -- measured fastest), 14 = the same without the skipping
+// staging, zero tiles of the diagonal block skipped -- measured fastest; round 6 measured a form whose workgroups walk over
+// several tiles, prefetching the next tile's first K slab during the epilogue: same bits, 6-10 % slower at every size,
+// scripts/dev/attic/k_predict_gemm_walk.hip.txt, profiles/r06_time_walk.log), 14 = the same without the skipping
 // (k_predict_gemm; production until round 2), 4 / 8 = 4 / 8 waves with register staging, 18 = 8 waves with LDS-DMA, 24 = LDS-DMA
 // with three 8-row buffers and two tiles in flight.  They agree to rounding (the 8-wave kernels sum the
 // row groups of the epilogue in another order).  The

@@ -13,7 +13,7 @@ import pytest
 
 from oracle import gp_ei_oracle as orc
 from spearmint_amd import dist as sd
-from spearmint_amd.engine import Engine, FLAG_PER_SEC
+from spearmint_amd.engine import Engine, FLAG_KEEP_MOMENTS, FLAG_PER_SEC
 from spearmint_amd.synthetic import synthetic_problem
 
 pytestmark = pytest.mark.gpu
