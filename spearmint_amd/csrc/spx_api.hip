@@ -170,6 +170,7 @@ void spx_destroy(spx_handle* h)
         for (DevBuf* b : bufs) b->release();
         h->pin_up.release();
         h->pin_res.release();
+        h->pin_stage.release();
         for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev_sync[i]);
         (void)hipEventDestroy(h->ev_t0);
@@ -260,6 +261,10 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "lean_poll")) { h->lean_poll = value < 0 ? -1 : (value != 0); return SPX_OK; }   // (spx_internal.h)
     if (!strcmp(name, "lean_zc")) { h->lean_zc = value < 0 ? -1 : (value != 0); return SPX_OK; }
+    if (!strcmp(name, "stage_copies")) {   // callers' small host buffers through the handle's page-locked staging buffer (1, default) or handed to the runtime as they are (0)
+        h->stage_copies = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
     if (!strcmp(name, "cov_flat")) {       // K(X*,X) launches of several residency rounds: equal contiguous shares (k_cov_flat; 1, default) or the 3-D grid (0)
         h->cov_flat = value < 0 ? -1 : (value != 0);
         return SPX_OK;
@@ -281,6 +286,52 @@ int spx_set_option(spx_handle* h, const char* name, int64_t value)
     return fail(SPX_ERR_ARG, "spx_set_option: unknown option '%s'", name);
 }
 
+// Copies between a CALLER's host buffer and the device.  The runtime's own path for pageable host memory (a pool of staging
+// chunks) stalls for 13-28 ms every few dozen small copies on this stack (profiles/r06_set_obs_spikes.log: one
+// spx_set_observations in five, median 0.03 ms) -- at Spearmint's operating sizes that is a whole next().  Buffers up to
+// SPX_STAGE_MAX go through the handle's own page-locked staging buffer instead (one host memcpy; larger ones are pinned in place by
+// the runtime, which does not show the stall).  stage_begin() at the start of an entry point (the stream is idle: every entry
+// point that copies synchronises before it returns); a host-to-device copy is queued on `s`, the caller synchronises as before.
+#define SPX_STAGE_MAX (8u << 20)
+static void stage_begin(spx_handle* h) { h->stage_off = 0; }
+static int stage_h2d(spx_handle* h, void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+    if (h->stage_copies == 0 || bytes > SPX_STAGE_MAX || h->stage_off + bytes > 4 * (size_t)SPX_STAGE_MAX) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        return SPX_OK;
+    }
+    if (h->pin_stage.cap < h->stage_off + bytes) {
+        if (h->stage_off) {           // (growing would move what earlier copies of this call still read)
+            HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+            return SPX_OK;
+        }
+        int rc = h->pin_stage.reserve(bytes > (1u << 20) ? bytes : (1u << 20));
+        if (rc) return rc;
+    }
+    char* st = (char*)h->pin_stage.p + h->stage_off;
+    memcpy(st, src, bytes);
+    h->stage_off += (bytes + 255) & ~(size_t)255;
+    HIPCHK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
+    return SPX_OK;
+}
+// device -> caller's buffer, complete on return (the stream is synchronised)
+static int stage_d2h(spx_handle* h, void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+    if (h->stage_copies == 0 || bytes > SPX_STAGE_MAX) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SPX_OK;
+    }
+    HIPCHK(hipStreamSynchronize(s));     // (nothing queued may still read the staging buffer)
+    int rc = h->pin_stage.reserve(bytes > (1u << 20) ? bytes : (1u << 20));
+    if (rc) return rc;
+    h->stage_off = 0;
+    HIPCHK(hipMemcpyAsync(h->pin_stage.p, src, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memcpy(dst, h->pin_stage.p, bytes);
+    return SPX_OK;
+}
+
 int spx_set_observations(spx_handle* h, const double* comp, const double* vals, int64_t N, int32_t D)
 {
     if (h && h->multi) return spx_multi_set_observations(h->multi, comp, vals, N, D);
@@ -293,8 +344,9 @@ int spx_set_observations(spx_handle* h, const double* comp, const double* vals, 
     h->N = N; h->D = D; h->Dp = padded_dim(D); h->Np = (int)round_up(N, SPX_PADN);
     if ((rc = h->comp.reserve((size_t)N * D * 8))) return rc;
     if ((rc = h->vals.reserve((size_t)N * 8))) return rc;
-    HIPCHK(hipMemcpyAsync(h->comp.p, comp, (size_t)N * D * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->vals.p, vals, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    stage_begin(h);
+    if ((rc = stage_h2d(h, h->comp.p, comp, (size_t)N * D * 8, h->stream))) return rc;
+    if ((rc = stage_h2d(h, h->vals.p, vals, (size_t)N * 8, h->stream))) return rc;
     double b = vals[0];
     for (int64_t i = 1; i < N; ++i) {  // np.min semantics: NaN propagates
         if (vals[i] != vals[i]) { b = vals[i]; break; }
@@ -318,7 +370,8 @@ int spx_set_candidates(spx_handle* h, const double* cand, int64_t M, int32_t D, 
     if (!h->have_obs) { h->D = D; h->Dp = padded_dim(D); }
     h->M = M; h->index_base = index_base;
     if ((rc = h->cand.reserve((size_t)M * D * 8))) return rc;
-    HIPCHK(hipMemcpyAsync(h->cand.p, cand, (size_t)M * D * 8, hipMemcpyHostToDevice, h->stream));
+    stage_begin(h);
+    if ((rc = stage_h2d(h, h->cand.p, cand, (size_t)M * D * 8, h->stream))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_cand = true; h->ran = false; h->ran_time = false;
     return SPX_OK;
@@ -347,7 +400,8 @@ int spx_set_time_model(spx_handle* h, const double* log_durs, const double* time
     int rc = ensure_init(h);
     if (rc) return rc;
     if ((rc = h->ldur.reserve((size_t)h->N * 8))) return rc;
-    HIPCHK(hipMemcpyAsync(h->ldur.p, log_durs, (size_t)h->N * 8, hipMemcpyHostToDevice, h->stream));
+    stage_begin(h);
+    if ((rc = stage_h2d(h, h->ldur.p, log_durs, (size_t)h->N * 8, h->stream))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     h->thyp_host.assign(time_hypers, time_hypers + (size_t)h->H * (3 + h->D));
     h->have_time = true; h->factored = false; h->ran = false; h->ran_time = false;
@@ -594,8 +648,7 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     if (defer_sync && !lean) HIPCHK(hipEventRecord(h->ev_fac, s));   // (spx_ei_step with two streams: alpha is ready)
     if (defer_sync) return SPX_OK;
     std::vector<int> info(nh);
-    HIPCHK(hipMemcpyAsync(info.data(), h->info.p, (size_t)nh * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = stage_d2h(h, info.data(), h->info.p, (size_t)nh * sizeof(int), s))) return rc;
     return finish_factor(h, info, tolerate_not_pd, lean);
 }
 
@@ -677,8 +730,9 @@ int spx_set_fantasies(spx_handle* h, const double* fant, const double* bests, in
     if ((rc = h->gammaS.reserve((size_t)H * S * Np * 8))) return rc;
     if ((rc = h->bests.reserve((size_t)H * S * 8))) return rc;
     hipStream_t s = h->stream;
-    HIPCHK(hipMemcpyAsync(h->fantT.p, ft.data(), ft.size() * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->bests.p, bests, (size_t)H * S * 8, hipMemcpyHostToDevice, s));
+    stage_begin(h);
+    if ((rc = stage_h2d(h, h->fantT.p, ft.data(), ft.size() * 8, s))) return rc;
+    if ((rc = stage_h2d(h, h->bests.p, bests, (size_t)H * S * 8, s))) return rc;
     for (int d = 0; d < H; ++d)   // Gamma_d = W_d (F_d - mean_d), one launch per draw, S columns each
         launch_gamma_multi(s, h->WT.d() + (size_t)d * Np * Np, h->fantT.d() + (size_t)d * S * n,
                            h->htab.d() + (size_t)d * SPX_HT, h->gammaS.d() + (size_t)d * S * Np, (int)n, Np, S);
@@ -1024,8 +1078,7 @@ int spx_get_ei_mean(spx_handle* h, double* out)
     if (rc) return rc;
     // after the all-reduce of a partitioned run: the GLOBAL mean (all draws of all ranks) of this handle's candidates
     const double* src = h->ran_2d ? h->ei_sum_full.d() + h->index_base : h->ei_mean.d();
-    HIPCHK(hipMemcpy(out, src, (size_t)h->M * 8, hipMemcpyDeviceToHost));
-    return SPX_OK;
+    return stage_d2h(h, out, src, (size_t)h->M * 8, h->stream);
 }
 
 int spx_get_ei_draws(spx_handle* h, double* out)
@@ -1037,7 +1090,7 @@ int spx_get_ei_draws(spx_handle* h, double* out)
     const int64_t M = h->M, Mp = round_up(M, SPX_BN);
     const int H = h->H;
     std::vector<double> tmp((size_t)H * Mp);
-    HIPCHK(hipMemcpy(tmp.data(), h->ei_draw.p, tmp.size() * 8, hipMemcpyDeviceToHost));
+    if ((rc = stage_d2h(h, tmp.data(), h->ei_draw.p, tmp.size() * 8, h->stream))) return rc;
     for (int64_t c = 0; c < M; ++c)
         for (int d = 0; d < H; ++d) out[(size_t)c * H + d] = tmp[(size_t)d * Mp + c];
     return SPX_OK;
@@ -1379,7 +1432,8 @@ int spx_ei_grad_batch(spx_handle* h, const double* points, int32_t P, double* ne
             h->alphaS_valid = true;
         }
     }
-    HIPCHK(hipMemcpyAsync(h->pt_x.p, points, (size_t)P * D * 8, hipMemcpyHostToDevice, s));
+    stage_begin(h);
+    if ((rc = stage_h2d(h, h->pt_x.p, points, (size_t)P * D * 8, s))) return rc;
     launch_point_cov(s, h->Xs.d(), h->s1.d(), h->hyp.d(), h->htab.d(), h->pt_x.d(), h->pt_k.d(), h->pt_dk.d(),
                      (int)N, Np, D, Dp, H, P, dev_kind(h));
     launch_trimv_multi(s, h->WT.d(), h->pt_k.d(), h->pt_t.d(), Np, H, P);        // t = W k
@@ -1394,8 +1448,7 @@ int spx_ei_grad_batch(spx_handle* h, const double* points, int32_t P, double* ne
                         S > 0 ? h->gammaS.d() : nullptr, S > 0 ? h->alphaS.d() : nullptr,
                         S > 0 ? h->bests.d() : nullptr, S > 0 ? h->pt_u.d() : nullptr);
     std::vector<double> out((size_t)H * P * (1 + D));
-    HIPCHK(hipMemcpyAsync(out.data(), h->pt_out.p, out.size() * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = stage_d2h(h, out.data(), h->pt_out.p, out.size() * 8, s))) return rc;
     LAUNCHCHK();
     // sum over draws in draw order, as grad_optimize_ei_over_hypers does (:368-380)
     for (int p = 0; p < P; ++p) {

@@ -179,6 +179,9 @@ struct spx_handle {
     DevBuf flow_flags;                                              // k_lean_flow: [H][nblk + 1][nblk] tile flags + [H][nblk] diagonal progress + the ticket and done counters
     size_t flow_flags_n = 0;                                        // ints the flags were zeroed for
     int flow_gen = 0;                                               // generation of the last call (flags are compared, not cleared)
+    PinBuf pin_stage;                                               // staging of the callers' small host buffers (stage_h2d / stage_d2h in spx_api.hip)
+    size_t stage_off = 0;
+    int stage_copies = -1;              // option "stage_copies"
     PinBuf pin_up, pin_res;                                         // hyper-parameter upload staging; log-likelihood results
     bool handoff_timeout = false;                                   // finish_factor saw info < 0
     bool flow_used = false;                                         // the last factorisation ran k_lean_flow
