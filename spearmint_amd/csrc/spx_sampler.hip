@@ -423,7 +423,7 @@ struct Mover {
             std::vector<Vec> out;
             if (!fdir || fprops <= 0) return out;
             for (int j = 0; j < fhyps && j < (int)zl.size(); ++j) {
-                Vec xn = at(dir, zl[(size_t)j], x0);               // what this move returns if proposal j is accepted
+                Vec xn(x0.size());                                 // what this move returns if proposal j is accepted
                 for (size_t i = 0; i < xn.size(); ++i) xn[i] = zl[(size_t)j] * dir[i] + x0[i];
                 if (!m->admissible(xn)) continue;
                 const size_t off = (size_t)j + 1;
