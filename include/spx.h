@@ -321,6 +321,8 @@ int spx_get_timings(spx_handle* h, double* ms, int64_t* launches, int n);
  *   "last_step_fused"  1 if the last EI pass ran as a one-kernel form (no K* / beta in memory; no fantasies);
  *   "last_step_skipped_padding"  1 if the last EI pass left the padding of N (to the GEMM's 128-row tiles) uncomputed
  *                      (option "gemm_partial", default on: same bits, up to -31 % per pass just above a multiple of 128);
+ *   "obs_dims"         D of the resident observations (0: none set);   "hip_runtime_version", "hip_driver_version", "clock_khz",
+ *                      "mem_clock_khz", "wall_clock_khz", "l2_bytes", "mem_bus_bits": what the process runs on (bench.py: platform);
  *   "ranks_seen"       size of the communicator the last exchange ran on (one record per rank in its table): the ranks of the attached communicator
  *                      (spx_comm_attach), the device slots of a multi-device handle, 1 otherwise.                  */
 int spx_get_stat(spx_handle* h, const char* name, int64_t* value);

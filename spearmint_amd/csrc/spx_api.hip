@@ -1312,7 +1312,11 @@ static int gp_logprob_once(spx_handle* h, double* out)
             }
         }
         if (!seen) HIPCHK(hipStreamSynchronize(h->stream));
-        else LAUNCHCHK();
+        LAUNCHCHK();
+        if (h->fused_ran && polled)      // (a launch that never ran -- refused, or a device error -- leaves its flags untouched)
+            for (int k = 0; k < h->H; ++k)
+                if (info_host[k] == SPX_POLL_SENTINEL)
+                    return fail(SPX_ERR_HIP, "spx_gp_logprob: the launch finished without delivering draw %d", k);
         memcpy(out, lp_host, (size_t)h->H * 8);
         memcpy(info.data(), info_host, (size_t)h->H * sizeof(int));
     } else {
@@ -1474,7 +1478,7 @@ int spx_get_stat(spx_handle* h, const char* name, int64_t* value)
 {
     if (!h || !name || !value) return fail(SPX_ERR_ARG, "spx_get_stat: null");
     if (h->multi) {
-        if (!strcmp(name, "ranks_seen") || !strcmp(name, "flow_fallbacks") || !strcmp(name, "flow_rearms"))
+        if (!strcmp(name, "ranks_seen") || !strcmp(name, "flow_fallbacks") || !strcmp(name, "flow_rearms") || !strcmp(name, "obs_dims"))
             return spx_multi_stat(h->multi, name, value);
         return fail(SPX_ERR_ARG, "spx_get_stat: ask the per-device handles (single-GPU handles only)");
     }
@@ -1483,6 +1487,7 @@ int spx_get_stat(spx_handle* h, const char* name, int64_t* value)
     else if (!strcmp(name, "flow_rearms")) *value = h->flow_rearms;           // times the handle went back to k_lean_flow after a fallback
     else if (!strcmp(name, "ranks_seen")) *value = h->comm ? h->ranks_seen : 1;   // size of the communicator the last exchange ran on (its table has one record per rank)
     else if (!strcmp(name, "n_cu")) *value = h->n_cu;
+    else if (!strcmp(name, "obs_dims")) *value = h->have_obs ? h->D : 0;   // D of the resident observations (0: none)
     else if (!strcmp(name, "last_step_fused")) *value = h->last_fused ? 1 : 0; // the last EI pass ran k_ei_fused128
     else if (!strcmp(name, "last_step_skipped_padding")) *value = h->last_skip_pad ? 1 : 0;   // ... skipped the padding of N (k_predict_gemm_tail)
     else if (!strcmp(name, "hip_runtime_version") || !strcmp(name, "hip_driver_version")) {

@@ -679,6 +679,7 @@ int spx_multi_info(spx_multi* m, int32_t* n_dev, int32_t* transport, int32_t* de
 int spx_multi_stat(spx_multi* m, const char* name, int64_t* value)
 {
     if (!strcmp(name, "ranks_seen")) { *value = m->n; return SPX_OK; }   // the device slots of the handle (= the size of its communicator)
+    if (!strcmp(name, "obs_dims")) { *value = m->N > 0 ? m->D : 0; return SPX_OK; }   // D of the resident observations (0: none)
     if (!strcmp(name, "flow_fallbacks") || !strcmp(name, "flow_rearms")) {   // summed over the devices' handles
         int64_t sum = 0;
         for (spx_handle* k : m->kids) {

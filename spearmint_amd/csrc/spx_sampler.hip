@@ -612,7 +612,12 @@ extern "C" {
 int spx_sample_hypers(spx_handle* h, const spx_sampler_cfg* cfg, spx_rng_state* rng, double* hyper_io, double* rows_out,
                       double* hist_io, int64_t* stats_out)
 {
-    if (!h) return fail(SPX_ERR_ARG, "spx_sample_hypers: null handle");
+    if (!h || !cfg) return fail(SPX_ERR_ARG, "spx_sample_hypers: null handle / configuration");
+    int64_t d = 0;      // (the rows the sampler hands to spx_set_hypers are 3 + cfg->D long: they must be the handle's)
+    int rc = spx_get_stat(h, "obs_dims", &d);
+    if (rc) return rc;
+    if (d == 0) return fail(SPX_ERR_ARG, "spx_sample_hypers: call spx_set_observations first");
+    if (d != cfg->D) return fail(SPX_ERR_ARG, "spx_sample_hypers: cfg->D = %d but the observations have D = %lld", cfg->D, (long long)d);
     return run_sampler(gpu_logprob, h, cfg, rng, hyper_io, rows_out, hist_io, stats_out);
 }
 

@@ -3,6 +3,7 @@ include/spx.h declares (no compute calls here)."""
 import os
 import re
 
+import numpy as np
 import pytest
 
 from spearmint_amd import engine
@@ -52,6 +53,11 @@ def test_create_is_lazy_and_arg_checks(lib):
         eng.set_hypers([[0.0, 1e-3, 1.0, 1.0]])      # observations not set yet
     with pytest.raises(ValueError):
         eng.ei_run()
+    # spx_sample_hypers: no observations -> an argument error, before anything is read through the configuration's D
+    cfg = engine.SamplerCfg(D=3, n_iter=1, noiseless=0, check_mean=1, amp2_prior_on_sqrt=1, lookahead=4, follow_props=0, follow_hyps=0,
+                            max_rows=32, noise_scale=0.1, amp2_scale=1.0, max_ls=2.0, vals_min=0.0, vals_max=1.0)
+    with pytest.raises(ValueError):
+        eng.sample_hypers(cfg, np.array([0.5, 1e-3, 1.0, 1.0, 1.0, 1.0]), np.zeros(12), rng_state=engine.RngState.from_numpy())
     eng.close()
 
 

@@ -764,6 +764,75 @@ def test_fused_loglikelihood_call_is_bit_identical(N, D, H, covar):
         eng.close()
 
 
+@pytest.mark.parametrize("name,N,D,args", [
+    ("GPEIOptChooser", 40, 3, "mcmc_iters=4,burnin=6,grid_subset=3"),
+    ("GPEIOptChooser", 300, 8, "mcmc_iters=5,burnin=5,grid_subset=4"),
+    ("GPEIChooser", 130, 5, "mcmc_iters=6"),
+    ("GPEIOptChooser", 200, 6, "mcmc_iters=4,burnin=4,grid_subset=3,noiseless=1"),
+    ("GPEIperSecChooser", 120, 4, "mcmc_iters=3,burnin=4,grid_subset=3"),
+])
+def test_native_sampler_on_libspx_is_the_python_sampler_chain(tmp_path, name, N, D, args):
+    """Round 6: `sampler=native` (spx_sample_hypers: the slice sampler's control flow, priors, speculation and numpy's
+    random stream as C++ inside libspx; the default) and `sampler=python` (util.slice_sample_batched around
+    Engine.gp_logprob, round 5) on the SAME log-likelihood kernels: the same hyper samples bit for bit, the same proposal,
+    the same generator state afterwards -- at the measured depth (auto) and at explicit depths, for the three choosers,
+    noiseless, and with a handle over three device slots."""
+    import importlib
+    from spearmint_amd.engine import MultiEngine
+    mod = importlib.import_module("spearmint_amd.chooser." + name)
+    rs = np.random.RandomState(N)
+    G = 400
+    grid = rs.rand(N + G, D)
+    values = np.full(N + G, np.nan)
+    values[:N] = np.sin(3 * grid[:N]).sum(axis=1) + 0.05 * rs.randn(N)
+    durations = np.full(N + G, np.nan)
+    durations[:N] = 1.0 + 3.0 * grid[:N, 0] + np.sin(5 * grid[:N, 1]) ** 2
+    complete, candidates, pending = np.arange(N), np.arange(N, N + G), np.array([], dtype=int)
+    got = {}
+    for tag, extra, multi in (("python", "sampler=python,lookahead=6,follow=0:0", False), ("native", "sampler=native", False),
+                              ("native-deep", "sampler=native,lookahead=8,follow=6:3", False),
+                              ("native-multi", "sampler=native,lookahead=5,follow=3:2", True)):
+        d = tmp_path / tag
+        d.mkdir()
+        ch = mod.init(str(d), args + ",use_multiprocessing=0," + extra)
+        if multi:
+            ch._eng = MultiEngine([0, 0, 0])
+        npr.seed(77)
+        job = ch.next(grid, values, durations, candidates, pending, complete)
+        got[tag] = (job, [np.concatenate(([h[0], h[1], h[2]], h[3])) for h in getattr(ch, "hyper_samples", [])] or [ch.current_hyper_row()],
+                    npr.get_state(), dict(ch.sampler_stats))
+        ch.engine().close()
+    ref = got["python"]
+    assert ref[3]["calls"] == 0
+    for tag in ("native", "native-deep", "native-multi"):
+        g = got[tag]
+        assert np.array_equal(np.array(g[1]), np.array(ref[1])), tag                      # the chain, bit for bit
+        assert np.array_equal(g[2][1], ref[2][1]) and g[2][2:] == ref[2][2:], tag          # the generator, draw for draw
+        if isinstance(ref[0], tuple):
+            assert g[0][0] == ref[0][0] and np.array_equal(g[0][1], ref[0][1]), tag
+        else:
+            assert g[0] == ref[0], tag
+        assert g[3]["calls"] > 0 and g[3]["moves"] > 0
+    assert got["native-deep"][3]["free_moves"] > 0
+
+
+def test_sampler_argument_errors(eng):
+    from spearmint_amd.engine import SamplerCfg, RngState
+    comp, cand, vals, hypers = synthetic_problem(50, 16, 4, 1, 5)
+    eng.set_observations(comp, vals)
+    cfg = SamplerCfg(D=5, n_iter=1, noiseless=0, check_mean=1, amp2_prior_on_sqrt=1, lookahead=4, follow_props=0, follow_hyps=0,
+                     max_rows=32, noise_scale=0.1, amp2_scale=1.0, max_ls=2.0, vals_min=float(vals.min()), vals_max=float(vals.max()))
+    with pytest.raises(ValueError):          # the observations have D = 4
+        eng.sample_hypers(cfg, np.concatenate((hypers[0], [1.0])), np.zeros(12), rng_state=RngState.from_numpy())
+    cfg.D = 4
+    cfg.lookahead = 0
+    with pytest.raises(ValueError):
+        eng.sample_hypers(cfg, hypers[0].copy(), np.zeros(12), rng_state=RngState.from_numpy())
+    cfg.lookahead = 4
+    rows, st = eng.sample_hypers(cfg, hypers[0].copy(), np.zeros(12), rng_state=RngState.from_numpy())
+    assert rows.shape == (1, 7) and st["iterations"] == 1 and st["moves"] == 5
+
+
 def test_step_argument_errors_leave_nothing_queued(eng):
     """spx_ei_step checks its flags BEFORE it queues the factorisation, and any later error exit of a pending
     step returns with the streams idle and without an unchecked factor."""
