@@ -211,7 +211,8 @@ int spx_ei_per_sec_grid(spx_handle* h,
  *   rows_out   n_iter rows [mean, noise, amp2, ls...]: the point after every iteration (NULL: not wanted)
  *   hist_io    12 doubles of bracket statistics the speculation learns from (zeros to start; keep between calls)
  *   stats_out  SPX_SAMPLER_NSTATS values: {spx_gp_logprob calls, hyper rows evaluated, slice moves, moves that needed no
- *              call, iterations completed, then calls by number of hyper rows: [5 + r] for r = 0 .. 32, [38] beyond} (NULL ok)
+ *              call, iterations completed, then calls by number of hyper rows: [5 + r] for r = 0 .. 32, [38] beyond, [39] nanoseconds
+ *              inside the log-likelihood calls, [40] nanoseconds in all} (NULL ok)
  *
  * Errors (the iteration that failed is left as the reference leaves it: a finished joint move is applied, an
  * unfinished sweep is not; `rng` is where the reference's generator would be; rows_out holds the iterations done;
@@ -219,7 +220,7 @@ int spx_ei_per_sec_grid(spx_handle* h,
  *   SPX_ERR_NOT_PD      a covariance the sampler really evaluated was not positive definite (spla.cholesky raises)
  *   SPX_ERR_SLICE_NAN   "Slice sampler got a NaN"          (util.py:59-61)
  *   SPX_ERR_SLICE_ZERO  "Slice sampler shrank to zero!"    (util.py:68-69)                                            */
-#define SPX_SAMPLER_NSTATS 39
+#define SPX_SAMPLER_NSTATS 41
 #define SPX_ERR_SLICE_NAN  -4
 #define SPX_ERR_SLICE_ZERO -5
 typedef struct spx_rng_state {      /* numpy.random.get_state(): ('MT19937', key, pos, has_gauss, cached_gaussian)     */

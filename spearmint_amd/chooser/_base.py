@@ -91,7 +91,7 @@ class GPEIBase(object):
         if self.sampler not in ("native", "python"):
             raise ValueError("sampler must be native or python (got %r)" % (sampler,))
         self._native_hist = None
-        self.sampler_stats = {"calls": 0, "rows": 0, "moves": 0, "free_moves": 0, "calls_by_rows": [0] * 34}
+        self.sampler_stats = {"calls": 0, "rows": 0, "moves": 0, "free_moves": 0, "ns_in_calls": 0, "ns_total": 0, "calls_by_rows": [0] * 34}
         # opt-in: have the driver's ExperimentGrid build its Sobol candidate grid with the HIP
         # generator (bit-identical; spearmint-lite rebuilds the grid on every invocation)
         self.gpu_sobol = _as_bool(gpu_sobol)
@@ -445,7 +445,7 @@ class GPEIBase(object):
                     raise
                 err = ex                    # (the chain stays where the reference's exception leaves it)
                 err.state_at_error = (hyper[0], hyper[2], hyper[1], hyper[3:].copy())
-            for k in ("calls", "rows", "moves", "free_moves"):
+            for k in ("calls", "rows", "moves", "free_moves", "ns_in_calls", "ns_total"):
                 self.sampler_stats[k] += st[k]
             self.sampler_stats["calls_by_rows"] = [a + b for a, b in zip(self.sampler_stats["calls_by_rows"], st["calls_by_rows"])]
             return [(r[0], r[2], r[1], r[3:].copy()) for r in rows], err

@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <chrono>
 #include <deque>
 #include <memory>
 #include <string>
@@ -206,6 +207,7 @@ struct Evaluator {
     std::unordered_map<std::string, std::pair<double, bool> > memo[2];   // this batch's rows and the batch before
     int64_t calls = 0, rows = 0;
     int64_t by_rows[34] = {0};   // calls by number of hyper rows (33: more than 32)
+    int64_t ns_in_calls = 0;     // wall time inside the log-likelihood callback
     int rc = 0;
 
     static std::string key_of(const double* r, int n) { return std::string((const char*)r, (size_t)n * 8); }
@@ -270,7 +272,9 @@ struct Evaluator {
         }
         const int n = (int)(R.size() / L);
         std::vector<double> lp((size_t)n);
+        const auto t0 = std::chrono::steady_clock::now();
         rc = fn(ctx, R.data(), n, lp.data());
+        ns_in_calls += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         if (rc) throw SliceError{rc};
         calls += 1; rows += n;
         by_rows[n > 32 ? 33 : n] += 1;
@@ -521,6 +525,8 @@ int run_sampler(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rn
     Vec ls(hyper_io + 3, hyper_io + 3 + D);
     int64_t calls = 0, rows = 0, moves = 0, free_moves = 0, done = 0;
     int64_t by_rows[34] = {0};
+    int64_t ns_calls = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
     int rc = SPX_OK;
     try {
         for (int it = 0; it < cfg->n_iter; ++it) {
@@ -542,8 +548,8 @@ int run_sampler(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rn
                 for (int i = 0; i < 3; ++i) dir[(size_t)i] = dir[(size_t)i] / nrm;
                 Uniforms u(&rng);
                 Vec x0 = {mean, amp2, noise};
-                struct Acc { int64_t &c, &r, &mv_, &f; int64_t* hb; Evaluator& e; Mover& m_; ~Acc() { c += e.calls; r += e.rows; mv_ += m_.moves; f += m_.free_moves; for (int q = 0; q < 34; ++q) hb[q] += e.by_rows[q]; } }
-                    acc{calls, rows, moves, free_moves, by_rows, ev, mv};
+                struct Acc { int64_t &c, &r, &mv_, &f; int64_t* hb; int64_t& ns; Evaluator& e; Mover& m_; ~Acc() { c += e.calls; r += e.rows; mv_ += m_.moves; f += m_.free_moves; ns += e.ns_in_calls; for (int q = 0; q < 34; ++q) hb[q] += e.by_rows[q]; } }
+                    acc{calls, rows, moves, free_moves, by_rows, ns_calls, ev, mv};
                 Vec nx = mv.move(dir, x0, u, nullptr, 0, 0);
                 mean = nx[0]; amp2 = nx[1]; noise = cfg->noiseless ? 1e-3 : nx[2];
             }
@@ -561,8 +567,8 @@ int run_sampler(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rn
                 rng.shuffle(order);
                 Uniforms u(&rng);
                 Vec cur = ls;
-                struct Acc { int64_t &c, &r, &mv_, &f; int64_t* hb; Evaluator& e; Mover& m_; ~Acc() { c += e.calls; r += e.rows; mv_ += m_.moves; f += m_.free_moves; for (int q = 0; q < 34; ++q) hb[q] += e.by_rows[q]; } }
-                    acc{calls, rows, moves, free_moves, by_rows, ev, mv};
+                struct Acc { int64_t &c, &r, &mv_, &f; int64_t* hb; int64_t& ns; Evaluator& e; Mover& m_; ~Acc() { c += e.calls; r += e.rows; mv_ += m_.moves; f += m_.free_moves; ns += e.ns_in_calls; for (int q = 0; q < 34; ++q) hb[q] += e.by_rows[q]; } }
+                    acc{calls, rows, moves, free_moves, by_rows, ns_calls, ev, mv};
                 for (int i = 0; i < D; ++i) {
                     Vec e((size_t)D, 0.0), e2;
                     e[(size_t)order[(size_t)i]] = 1.0;
@@ -590,6 +596,8 @@ int run_sampler(spx_logprob_fn fn, void* ctx, const spx_sampler_cfg* cfg, spx_rn
     if (stats_out) {
         stats_out[0] = calls; stats_out[1] = rows; stats_out[2] = moves; stats_out[3] = free_moves; stats_out[4] = done;
         for (int q = 0; q < 34; ++q) stats_out[5 + q] = by_rows[q];
+        stats_out[39] = ns_calls;
+        stats_out[40] = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
     }
     if (rc == SPX_ERR_NOT_PD) return fail(rc, "slice sampler: covariance not positive definite at a point the sampler evaluated");
     if (rc == SPX_ERR_SLICE_NAN) return fail(rc, "Slice sampler got a NaN");

@@ -171,7 +171,7 @@ class SpxError(RuntimeError):
 
 def _sampler_result(lib, rc, rows, stats):
     st = {"calls": int(stats[0]), "rows": int(stats[1]), "moves": int(stats[2]), "free_moves": int(stats[3]),
-          "iterations": int(stats[4]), "calls_by_rows": [int(v) for v in stats[5:39]]}
+          "iterations": int(stats[4]), "calls_by_rows": [int(v) for v in stats[5:39]], "ns_in_calls": int(stats[39]), "ns_total": int(stats[40])}
     if rc == SPX_OK:
         return rows, st
     msg = lib.spx_last_error()
@@ -210,7 +210,7 @@ def sample_hypers_with(logprob_rows, cfg, hyper, hist, rng_state=None, lib=None)
             return SPX_ERR_ARG
     rng = RngState.from_numpy() if rng_state is None else rng_state
     rows = np.empty((int(cfg.n_iter), 3 + D))
-    stats = np.zeros(39, dtype=np.int64)
+    stats = np.zeros(41, dtype=np.int64)
     rc = lib.spx_sample_hypers_with(LOGPROB_FN(cb), None, ctypes.byref(cfg), ctypes.byref(rng), _dp(hyper), _dp(rows),
                                     _dp(hist), stats.ctypes.data_as(_c_int64_p))
     if rng_state is None:
@@ -503,7 +503,7 @@ class Engine(object):
         import numpy.random as npr
         rng = RngState.from_numpy() if rng_state is None else rng_state
         rows = np.empty((int(cfg.n_iter), 3 + int(cfg.D)))
-        stats = np.zeros(39, dtype=np.int64)
+        stats = np.zeros(41, dtype=np.int64)
         rc = self._lib.spx_sample_hypers(self._h, ctypes.byref(cfg), ctypes.byref(rng), _dp(hyper), _dp(rows), _dp(hist),
                                          stats.ctypes.data_as(_c_int64_p))
         if rng_state is None:
