@@ -525,9 +525,12 @@ static int do_factor(spx_handle* h, bool tolerate_not_pd, bool lean = false, boo
     // the call is the upload of the hyper rows and ONE launch.  (Dp <= 64: a block's scaled rows fit the kernel's LDS tile.)
     const bool fused = fused_early;
     h->fused_ran = fused;
-    if (fused && h->info_clean_ptr != h->info.p) {     // the not-PD flags: zero once; the fused launch leaves them zero
+    // the not-PD flags: zeroed once per allocation; the fused launch leaves them zero.  (Address AND size: a buffer that grew may
+    // come back at the address the smaller one had -- its new words are not the zeros the old ones were.)
+    if (fused && (h->info_clean_ptr != h->info.p || h->info_clean_bytes != h->info.cap)) {
         HIPCHK(hipMemsetAsync(h->info.p, 0, h->info.cap, s));
         h->info_clean_ptr = h->info.p;
+        h->info_clean_bytes = h->info.cap;
     }
     if (!fused) h->info_clean_ptr = nullptr;
     // x / ls and, in the same launch, the second operand pre-multiplied by 2 (gp.py:50; exact)

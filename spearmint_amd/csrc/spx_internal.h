@@ -124,7 +124,8 @@ struct spx_handle {
     double* fused_lp = nullptr;         // (spx_gp_logprob -> do_factor: pinned destinations of the fused form's results)
     int* fused_info = nullptr;
     bool fused_ran = false;             // the last do_factor took the fused form
-    const void* info_clean_ptr = nullptr;   // the not-PD flags at this address are all zero (left so by the fused launch)
+    const void* info_clean_ptr = nullptr;   // the not-PD flags at this address ...
+    size_t info_clean_bytes = 0;            // ... in a buffer of this size are all zero (left so by the fused launch)
     int cov_flat = -1;                  // option "cov_flat": k_cov_flat for multi-round K(X*,X) launches 1 / 0 / -1 = default (on)
     int gemm_partial = -1;              // option "gemm_partial": skip the padding of N in the EI pass 1 / 0 / -1 = default (on)
     bool last_skip_pad = false;         // the last EI pass did

@@ -764,6 +764,33 @@ def test_fused_loglikelihood_call_is_bit_identical(N, D, H, covar):
         eng.close()
 
 
+def test_fused_loglikelihood_flags_survive_a_growing_batch():
+    """The one-launch log-likelihood call keeps its not-PD flags clean by itself (no clearing launch): they are zeroed once per
+    ALLOCATION.  A flag buffer that grows may be handed the address the smaller one had -- its new words are not zeros
+    (round 6: a fresh engine whose first call has 1 row and whose second has 17 reported a spurious not-PD draw, one run in
+    a few).  Fresh engines, batches that grow and shrink: every value equals the three-launch form's, no draw is reported."""
+    from spearmint_amd.engine import Engine
+    comp, cand, vals, hypers = synthetic_problem(40, 16, 3, 32, 97)
+    ref = Engine(0)
+    ref.set_option("lean_one", 0)
+    ref.set_observations(comp, vals)
+    want = {}
+    for H in (1, 17, 3, 32, 8, 24):
+        ref.set_hypers(hypers[:H])
+        want[H] = ref.gp_logprob()
+        assert np.isfinite(want[H]).all()
+    ref.close()
+    for trial in range(25):
+        eng = Engine(0)
+        eng.set_observations(comp, vals)
+        for H in ((1, 17, 3, 32, 8, 24) if trial % 2 == 0 else (3, 8, 17, 24, 32, 1)):
+            eng.set_hypers(hypers[:H])
+            got = eng.gp_logprob()
+            assert np.array_equal(got, want[H]), (trial, H)
+            assert eng.not_pd_info()[0] < 0
+        eng.close()
+
+
 @pytest.mark.parametrize("name,N,D,args", [
     ("GPEIOptChooser", 40, 3, "mcmc_iters=4,burnin=6,grid_subset=3"),
     ("GPEIOptChooser", 300, 8, "mcmc_iters=5,burnin=5,grid_subset=4"),
