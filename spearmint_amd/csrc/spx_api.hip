@@ -1292,7 +1292,7 @@ static int gp_logprob_once(spx_handle* h, double* out)
     if (polled) for (int k = 0; k < h->H; ++k) info_host[k] = SPX_POLL_SENTINEL;   // (coherent pinned memory: in place before the launch is queued)
     rc = do_factor(h, true, true, true);   // K(X,X), Cholesky, forward solve -- no inverse; queued, not yet synchronised
     h->fused_lp = nullptr; h->fused_info = nullptr;
-    if (rc) return rc;
+    if (rc) { h->info_clean_ptr = nullptr; return rc; }
     if ((rc = h->lp.reserve((size_t)h->H * 8))) return rc;
     std::vector<int> info(h->H);
     if (h->lean_tiled) {
@@ -1303,6 +1303,9 @@ static int gp_logprob_once(spx_handle* h, double* out)
         // signal are ~7 us of a 42 us call).  What is still running then -- other workgroups' last instructions, the ticket
         // reset -- is ordered in front of whatever this stream is given next.  Bounded: after 20 ms (a long call at N = 8192
         // takes 10) the stream is synchronised the ordinary way.
+        // (the device-side flags count as clean again only once this call is known to have ended well)
+        const void* const clean_ptr = h->info_clean_ptr;
+        if (h->fused_ran) h->info_clean_ptr = nullptr;
         bool seen = false;
         if (h->fused_ran && polled) {
             volatile int* fl = (volatile int*)info_host;
@@ -1320,6 +1323,13 @@ static int gp_logprob_once(spx_handle* h, double* out)
             for (int k = 0; k < h->H; ++k)
                 if (info_host[k] == SPX_POLL_SENTINEL)
                     return fail(SPX_ERR_HIP, "spx_gp_logprob: the launch finished without delivering draw %d", k);
+        // a hand-off that timed out: a workgroup that gives up later than the draw's reducing item leaves -1 behind it -- the
+        // device-side flags are then zeroed again before the next one-launch call
+        if (h->fused_ran) {
+            bool timed_out = false;
+            for (int k = 0; k < h->H; ++k) timed_out |= info_host[k] < 0;
+            if (!timed_out) h->info_clean_ptr = clean_ptr;
+        }
         memcpy(out, lp_host, (size_t)h->H * 8);
         memcpy(info.data(), info_host, (size_t)h->H * sizeof(int));
     } else {
