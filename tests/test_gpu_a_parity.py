@@ -860,6 +860,35 @@ def test_sampler_argument_errors(eng):
     assert rows.shape == (1, 7) and st["iterations"] == 1 and st["moves"] == 5
 
 
+def test_staged_host_copies_change_nothing(eng):
+    """Round 6: callers' small host buffers travel through the handle's page-locked staging buffer (option stage_copies, default
+    on) instead of the runtime's path for pageable memory: the same results bit for bit -- EI grid with mean and draws, the
+    log-likelihood, the refinement objective, pending fantasies -- and buffers above the staging limit (8 MB) still arrive."""
+    comp, cand, vals, hypers, log_durs, th = synthetic_problem(150, 9000, 6, 3, 41, per_sec=True)
+    big = synthetic_problem(150, 200000, 6, 1, 42)[1]          # 9.6 MB of candidates: above the limit
+    out = []
+    for on in (0, 1):
+        eng.set_option("stage_copies", on)
+        a = eng.ei_grid(comp, vals, cand, hypers, want_draws=True)
+        p = eng.ei_per_sec_grid(comp, vals, log_durs, cand, hypers, th, want_draws=True)
+        eng.set_observations(comp, vals); eng.set_hypers(hypers)
+        lp = eng.gp_logprob()
+        eng.set_candidates(cand[:4000]); eng.factor()
+        f, g = eng.ei_grad_batch(cand[:7])
+        rs = np.random.RandomState(1)
+        fant = vals[None, :, None] + 0.1 * rs.randn(3, 150, 5)
+        eng.set_fantasies(fant, fant.min(axis=1)); eng.ei_run()
+        fm = eng.ei_mean()
+        b = eng.ei_grid(comp, vals, big, hypers[:1], want_mean=True)
+        out.append((a, p, lp, f, g, fm, b))
+    eng.set_option("stage_copies", -1)
+    x, y = out
+    assert x[0][0] == y[0][0] and np.array_equal(x[0][2], y[0][2]) and np.array_equal(x[0][3], y[0][3])
+    assert x[1][0] == y[1][0] and np.array_equal(x[1][3], y[1][3])
+    assert np.array_equal(x[2], y[2]) and np.array_equal(x[3], y[3]) and np.array_equal(x[4], y[4]) and np.array_equal(x[5], y[5])
+    assert x[6][0] == y[6][0] and np.array_equal(x[6][2], y[6][2])
+
+
 def test_step_argument_errors_leave_nothing_queued(eng):
     """spx_ei_step checks its flags BEFORE it queues the factorisation, and any later error exit of a pending
     step returns with the streams idle and without an unchecked factor."""
