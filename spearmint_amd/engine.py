@@ -189,37 +189,6 @@ def _sampler_result(lib, rc, rows, stats):
     raise err
 
 
-def sample_hypers_with(logprob_rows, cfg, hyper, hist, rng_state=None, lib=None):
-    """spx_sample_hypers_with: the library's sampler on a caller-supplied log-likelihood
-    `logprob_rows(rows[n, 3 + D]) -> lp[n]` (-inf = not positive definite).  No GPU, no handle -- the CPU tests' way to
-    hold the native sampler to the reference's chain; the choosers never use it."""
-    import numpy.random as npr
-    lib = load_library(lib)
-    D = int(cfg.D)
-    failure = []
-
-    def cb(ctx, rows_p, n, out_p):
-        try:
-            rows = np.ctypeslib.as_array(rows_p, shape=(n, 3 + D)).copy()
-            lp = np.asarray(logprob_rows(rows), dtype=np.float64)
-            for i in range(n):
-                out_p[i] = lp[i]
-            return 0
-        except BaseException as ex:        # must not unwind through C
-            failure.append(ex)
-            return SPX_ERR_ARG
-    rng = RngState.from_numpy() if rng_state is None else rng_state
-    rows = np.empty((int(cfg.n_iter), 3 + D))
-    stats = np.zeros(41, dtype=np.int64)
-    rc = lib.spx_sample_hypers_with(LOGPROB_FN(cb), None, ctypes.byref(cfg), ctypes.byref(rng), _dp(hyper), _dp(rows),
-                                    _dp(hist), stats.ctypes.data_as(_c_int64_p))
-    if rng_state is None:
-        npr.set_state(rng.to_numpy())
-    if failure:
-        raise failure[0]
-    return _sampler_result(lib, rc, rows, stats)
-
-
 TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "host"}
 
 

@@ -7,6 +7,40 @@ import numpy as np
 from oracle import gp_ei_oracle as orc
 
 
+def sample_hypers_with(logprob_rows, cfg, hyper, hist, rng_state=None, lib=None):
+    """spx_sample_hypers_with: the library's sampler on a caller-supplied log-likelihood
+    `logprob_rows(rows[n, 3 + D]) -> lp[n]` (-inf = not positive definite).  No GPU, no handle -- the CPU tests' way to
+    hold the native sampler to the reference's chain.  It lives under tests/: the product package binds no host-evaluator
+    path (spearmint_amd/engine.py declares the symbol's prototype with the rest of include/spx.h and never calls it)."""
+    import numpy.random as npr
+    from spearmint_amd.engine import (load_library, RngState, LOGPROB_FN, SPX_ERR_ARG, _dp, _c_int64_p, _sampler_result)
+    import ctypes
+    lib = load_library(lib)
+    D = int(cfg.D)
+    failure = []
+
+    def cb(ctx, rows_p, n, out_p):
+        try:
+            rows = np.ctypeslib.as_array(rows_p, shape=(n, 3 + D)).copy()
+            lp = np.asarray(logprob_rows(rows), dtype=np.float64)
+            for i in range(n):
+                out_p[i] = lp[i]
+            return 0
+        except BaseException as ex:        # must not unwind through C
+            failure.append(ex)
+            return SPX_ERR_ARG
+    rng = RngState.from_numpy() if rng_state is None else rng_state
+    rows = np.empty((int(cfg.n_iter), 3 + D))
+    stats = np.zeros(41, dtype=np.int64)
+    rc = lib.spx_sample_hypers_with(LOGPROB_FN(cb), None, ctypes.byref(cfg), ctypes.byref(rng), _dp(hyper), _dp(rows),
+                                    _dp(hist), stats.ctypes.data_as(_c_int64_p))
+    if rng_state is None:
+        npr.set_state(rng.to_numpy())
+    if failure:
+        raise failure[0]
+    return _sampler_result(lib, rc, rows, stats)
+
+
 class OracleEngine(object):
     def __init__(self, covar="Matern52"):
         self.calls = []
@@ -63,13 +97,12 @@ class OracleEngine(object):
         """Engine.sample_hypers on a box without a GPU: libspx's OWN sampler (spx_sample_hypers_with: the same C++ control
         flow, priors, speculation and random stream the GPU path runs) with the oracle's data term as the log-likelihood
         callback -- so the CPU tests drive the native sampler through the choosers exactly as the GPU path does."""
-        from spearmint_amd import engine as real
 
         def rows_lp(rows):
             self.set_hypers(rows)
             self.native_calls.append(len(rows))
             return self.gp_logprob()
-        return real.sample_hypers_with(rows_lp, cfg, hyper, hist, rng_state=rng_state)
+        return sample_hypers_with(rows_lp, cfg, hyper, hist, rng_state=rng_state)
 
     def get_factor(self, draw, want_K=True, want_L=True, want_alpha=True):
         return None, self.chols[draw], None

@@ -19,6 +19,7 @@ import numpy.random as npr
 import pytest
 
 from spearmint_amd import engine as E
+from tests import helpers as H
 from spearmint_amd import hostgp, util
 from spearmint_amd.chooser import GPEIChooser, GPEIOptChooser
 
@@ -95,7 +96,7 @@ def test_native_sampler_is_the_reference_chain(mod, D, N, noiseless, la, fo):
     ch._real_init(D, vals)
     hyper, hist, sizes = ch.current_hyper_row().copy(), np.zeros(12), []
     npr.seed(5)
-    rows, st = E.sample_hypers_with(_rows_lp(comp, vals, sizes), _cfg(ch, D, vals, n_iter, noiseless, la, fo), hyper, hist)
+    rows, st = H.sample_hypers_with(_rows_lp(comp, vals, sizes), _cfg(ch, D, vals, n_iter, noiseless, la, fo), hyper, hist)
     s_got = npr.get_state()
     assert np.array_equal(rows, np.array(want))                    # bit for bit
     assert np.array_equal(s_got[1], s_want[1]) and s_got[2:] == s_want[2:]
@@ -111,7 +112,7 @@ def test_native_sampler_is_the_reference_chain(mod, D, N, noiseless, la, fo):
     hyper2, hist2 = ch2.current_hyper_row().copy(), np.zeros(12)
     npr.seed(5)
     for k in range(n_iter):
-        r1, _ = E.sample_hypers_with(_rows_lp(comp, vals), _cfg(ch2, D, vals, 1, noiseless, la, fo), hyper2, hist2)
+        r1, _ = H.sample_hypers_with(_rows_lp(comp, vals), _cfg(ch2, D, vals, 1, noiseless, la, fo), hyper2, hist2)
         assert np.array_equal(r1[0], want[k])
     assert np.array_equal(npr.get_state()[1], s_want[1])
 
@@ -124,7 +125,7 @@ def test_cross_move_speculation_saves_calls_not_accuracy():
     for fo in ((0, 0), (4, 2), (6, 3)):
         hyper, hist = ch.current_hyper_row().copy(), np.zeros(12)
         npr.seed(9)
-        rows, st = E.sample_hypers_with(_rows_lp(comp, vals), _cfg(ch, 8, vals, 20, 0, 8, fo), hyper, hist)
+        rows, st = H.sample_hypers_with(_rows_lp(comp, vals), _cfg(ch, 8, vals, 20, 0, 8, fo), hyper, hist)
         out[fo] = (rows, st, npr.get_state())
     for fo in ((4, 2), (6, 3)):
         assert np.array_equal(out[fo][0], out[(0, 0)][0]) and np.array_equal(out[fo][2][1], out[(0, 0)][2][1])
@@ -180,7 +181,7 @@ def test_native_sampler_raises_what_the_reference_raises():
         hyper, hist = ch.current_hyper_row().copy(), np.zeros(12)
         npr.seed(13)
         with pytest.raises(exc) as info:
-            E.sample_hypers_with(rows_lp, cfg, hyper, hist)
+            H.sample_hypers_with(rows_lp, cfg, hyper, hist)
         assert 0 < len(done) < 6                                         # the failure really came mid-run
         assert np.array_equal(info.value.rows_done, np.array(done))       # the iterations before it are delivered
         assert np.array_equal(hyper, at_error)                            # a finished joint move applied, the sweep not
@@ -190,9 +191,9 @@ def test_native_sampler_raises_what_the_reference_raises():
     def boom(rows):
         raise RuntimeError("evaluator failed")
     with pytest.raises(RuntimeError):
-        E.sample_hypers_with(boom, cfg, ch.current_hyper_row().copy(), np.zeros(12))
+        H.sample_hypers_with(boom, cfg, ch.current_hyper_row().copy(), np.zeros(12))
     with pytest.raises(ValueError):
-        E.sample_hypers_with(good, _cfg(ch, 3, vals, 2, 0, 0, (0, 0)), ch.current_hyper_row().copy(), np.zeros(12))
+        H.sample_hypers_with(good, _cfg(ch, 3, vals, 2, 0, 0, (0, 0)), ch.current_hyper_row().copy(), np.zeros(12))
 
 
 def test_chooser_default_is_the_native_sampler_and_equals_the_python_one(tmp_path):
