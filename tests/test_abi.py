@@ -80,6 +80,22 @@ def test_product_never_imports_oracle():
                     os.path.join(d, f)
 
 
+def test_product_never_calls_the_host_evaluator_entry():
+    """spx_sample_hypers_with (the library's sampler on a caller-supplied log-likelihood: how the CPU tests pin the native
+    sampler) is declared with the rest of the ABI and never called by the product: the choosers' sampler is
+    spx_sample_hypers on the GPU, and the Python package has no wrapper of the callback form (it lives in tests/helpers.py)."""
+    pkg = os.path.join(ROOT, "spearmint_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(d, f)).read()
+                uses = [ln for ln in txt.splitlines() if "sample_hypers_with" in ln]
+                assert all(ln.strip().startswith('"spx_sample_hypers_with":') for ln in uses), (f, uses)
+    for f in ("dropin/chooser/GPEIChooser.py", "dropin/chooser/GPEIOptChooser.py", "dropin/chooser/GPEIperSecChooser.py", "bench.py",
+              "__graft_entry__.py"):
+        assert "sample_hypers_with" not in open(os.path.join(ROOT, f)).read()
+
+
 def test_multi_handle_creation_is_lazy_and_checked(lib):
     """spx_create_multi: argument checks, and -- with repeated device ids, which use the host transport --
     no GPU is touched until the first call that needs one (the chooser is constructed before a fork)."""
