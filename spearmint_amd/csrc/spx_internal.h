@@ -72,7 +72,9 @@ struct PinBuf {
         if (bytes <= cap) return SPX_OK;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         if (bytes < 4096) bytes = 4096;
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        // coherent (fine-grained) whatever HIP_HOST_COHERENT says: kernels read hyper rows out of these buffers and store results
+        // and completion flags into them that the host watches while the launch is still running (spx_gp_logprob)
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocCoherent);
         if (e != hipSuccess) {
             p = nullptr;
             (void)hipGetLastError();
