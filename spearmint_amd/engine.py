@@ -470,6 +470,9 @@ class Engine(object):
         would be (rng_state: use / update this RngState instead).  Returns (rows[n_iter, 3 + D], stats dict).  Raises
         what the reference raises: LinAlgError (not positive definite), SliceSamplerError (NaN / shrank to zero)."""
         import numpy.random as npr
+        for name, a, n in (("hyper", hyper, 3 + int(cfg.D)), ("hist", hist, 12)):     # updated in place: no silent copies
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == (n,)):
+                raise ValueError("%s must be a contiguous float64 array of %d entries" % (name, n))
         rng = RngState.from_numpy() if rng_state is None else rng_state
         rows = np.empty((int(cfg.n_iter), 3 + int(cfg.D)))
         stats = np.zeros(41, dtype=np.int64)

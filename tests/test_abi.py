@@ -58,6 +58,10 @@ def test_create_is_lazy_and_arg_checks(lib):
                             max_rows=32, noise_scale=0.1, amp2_scale=1.0, max_ls=2.0, vals_min=0.0, vals_max=1.0)
     with pytest.raises(ValueError):
         eng.sample_hypers(cfg, np.array([0.5, 1e-3, 1.0, 1.0, 1.0, 1.0]), np.zeros(12), rng_state=engine.RngState.from_numpy())
+    with pytest.raises(ValueError):          # a hyper row of the wrong length never reaches the library
+        eng.sample_hypers(cfg, np.zeros(5), np.zeros(12), rng_state=engine.RngState.from_numpy())
+    with pytest.raises(ValueError):
+        eng.sample_hypers(cfg, np.zeros(6), np.zeros(11), rng_state=engine.RngState.from_numpy())
     eng.close()
 
 
