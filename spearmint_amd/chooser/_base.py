@@ -71,7 +71,8 @@ class GPEIBase(object):
         # costs 0.067 ms up to N = 128 whether it carries one hyper row or six (one launch for the factorisation, results
         # written into pinned host memory), a host evaluation 0.022 ms at N = 8, 0.030 at 32, 0.049 at 64, 0.081 at 96, 0.22
         # at 128; a slice move needs ~4.4 evaluations one after the other on the host or ~1.3 speculative batches on the GPU:
-        # break-even near N = 10, "auto" switches at 16.  (N = 2048: 0.58 ms per GPU call vs 250 ms.)
+        # break-even near N = 10, "auto" switches at 16 for the Python batched sampler (round 6: at 2 for the native one, see
+        # _use_gpu_logprob).  (N = 2048: 0.58 ms per GPU call vs 250 ms.)
         self.gpu_logprob = str(gpu_logprob)
         # same choice for the EI + gradient objective of the local refinement (spx_ei_grad_batch).  There the GPU wins at
         # every size (scripts/dev/refine_threshold.py, 10 draws: one call for all 20 refinement points 0.06 ms from N = 8 to
@@ -169,8 +170,12 @@ class GPEIBase(object):
 
     # -- log-likelihood data term: host or GPU ------------------------------------------
     def _use_gpu_logprob(self, n):
-        if self.gpu_logprob == "auto":   # threshold measured on one MI355X box; SPX_LOGPROB_MIN_N overrides it
-            return n >= int(os.environ.get("SPX_LOGPROB_MIN_N", "16"))
+        if self.gpu_logprob == "auto":   # thresholds measured on one MI355X box; SPX_LOGPROB_MIN_N overrides them
+            # (round 6: with the sampler inside the library a call costs 35 us and nothing between calls -- a whole next() at
+            # N = 2 ... 32 takes 0.011-0.014 s against 0.019-0.026 s with the reference's serial sampler on the host,
+            # profiles/r06_logprob_threshold.log: the GPU from the first GP proposal on.  The Python batched sampler breaks even
+            # near N = 10, as measured in round 3: 16.)
+            return n >= int(os.environ.get("SPX_LOGPROB_MIN_N", "2" if self.sampler == "native" else "16"))
         return _as_bool(self.gpu_logprob)
 
     def _use_gpu_refine(self, n):
